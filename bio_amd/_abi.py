@@ -1,0 +1,112 @@
+"""ctypes mirror of include/bio_pileup.h.  Keep field order identical to the header."""
+import ctypes as C
+import os
+
+BP_ROW_U32 = 11
+BP_OK, BP_EINVAL, BP_EDEVICE, BP_ENOMEM, BP_EDATA, BP_EUNSORTED = 0, -1, -2, -3, -4, -5
+STRAND_NONE, STRAND_FWD, STRAND_REV = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbiopileup.so")
+SYNTH_LIB_PATH = os.path.join(_HERE, "libbpsynth.so")
+
+
+class bp_opts(C.Structure):
+    _fields_ = [
+        ("clip", C.c_int32),
+        ("flag_exclude", C.c_int32),
+        ("mapq", C.c_int32),
+        ("max_read_len", C.c_int32),
+        ("max_read_span", C.c_int32),
+        ("min_base_qual", C.c_int32),
+        ("stitch", C.c_int32),
+        ("ignore_strand", C.c_int32),
+        ("strand_req", C.c_int32),
+        ("device", C.c_int32),
+        ("reserved", C.c_int32 * 6),
+    ]
+
+
+class bp_record_batch(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("ref_id", C.POINTER(C.c_int32)),
+        ("pos", C.POINTER(C.c_int32)),
+        ("mate_ref_id", C.POINTER(C.c_int32)),
+        ("mate_pos", C.POINTER(C.c_int32)),
+        ("flags", C.POINTER(C.c_uint16)),
+        ("mapq", C.POINTER(C.c_uint8)),
+        ("n_cigar", C.POINTER(C.c_uint32)),
+        ("l_seq", C.POINTER(C.c_uint32)),
+        ("cigar_off", C.POINTER(C.c_uint64)),
+        ("cigar", C.POINTER(C.c_uint32)),
+        ("seq_off", C.POINTER(C.c_uint64)),
+        ("seq", C.POINTER(C.c_uint8)),
+        ("qual_off", C.POINTER(C.c_uint64)),
+        ("qual", C.POINTER(C.c_uint8)),
+        ("name_off", C.POINTER(C.c_uint64)),
+        ("name", C.POINTER(C.c_uint8)),
+    ]
+
+
+class bp_timing(C.Structure):
+    _fields_ = [
+        ("plan_ms", C.c_float),
+        ("pileup_ms", C.c_float),
+        ("total_ms", C.c_float),
+        ("n_windows", C.c_int64),
+        ("n_items", C.c_int64),
+    ]
+
+
+EXPORTS = [
+    "bp_init", "bp_create", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute",
+    "bp_num_rows", "bp_rows", "bp_rows_device", "bp_column_sums", "bp_get_timing",
+    "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
+]
+
+_lib = None
+
+
+def load():
+    """Load libbiopileup.so.  Raises if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  bio_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.bp_init.argtypes = [C.c_int32]
+    lib.bp_init.restype = C.c_int
+    lib.bp_create.argtypes = [C.POINTER(bp_opts), C.c_int32, C.POINTER(C.c_int32), C.POINTER(H)]
+    lib.bp_create.restype = C.c_int
+    lib.bp_set_bed.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    lib.bp_set_bed.restype = C.c_int
+    lib.bp_submit.argtypes = [H, C.POINTER(bp_record_batch)]
+    lib.bp_submit.restype = C.c_int
+    lib.bp_finish.argtypes = [H]
+    lib.bp_finish.restype = C.c_int
+    lib.bp_compute.argtypes = [H]
+    lib.bp_compute.restype = C.c_int
+    lib.bp_num_rows.argtypes = [H]
+    lib.bp_num_rows.restype = C.c_int64
+    lib.bp_rows.argtypes = [H, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                            C.POINTER(C.c_uint32)]
+    lib.bp_rows.restype = C.c_int
+    lib.bp_rows_device.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.bp_rows_device.restype = C.c_int
+    lib.bp_column_sums.argtypes = [H, C.POINTER(C.c_uint64)]
+    lib.bp_column_sums.restype = C.c_int
+    lib.bp_get_timing.argtypes = [H, C.POINTER(bp_timing)]
+    lib.bp_get_timing.restype = C.c_int
+    lib.bp_algorithmic_bytes.argtypes = [H]
+    lib.bp_algorithmic_bytes.restype = C.c_int64
+    lib.bp_last_error.argtypes = [H]
+    lib.bp_last_error.restype = C.c_char_p
+    lib.bp_destroy.argtypes = [H]
+    lib.bp_destroy.restype = None
+    _lib = lib
+    return lib

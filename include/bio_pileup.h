@@ -1,0 +1,162 @@
+/*
+ * bio_pileup.h -- C ABI of libbiopileup.so, the MI355X (gfx950) implementation of the
+ * grailbio/bio pileup/snp hot path.
+ *
+ * The reference has no FFI for this path: the seam is the Go method
+ *   pileupMutable.processShard + flushTo*      (pileup/snp/pileup.go:661-810, :513-585)
+ * driven per job by pileupSNPMain              (pileup/snp/pileup.go:862-939).
+ * One bp_handle replaces one job's {pileupMutable, refContext, pileupContext,
+ * pileupShardContext} (pileup.go:179-187, :161-172, :212-220, :653-659).  A cgo shim calls
+ * these entry points instead of running the ring-buffer loop; see INTEGRATION.md.
+ *
+ * All signatures are plain C: pointers, sizes, fixed-width ints.  Every call returns 0 on
+ * success and a negative BP_E* code on failure; bp_last_error() returns the message (for
+ * data errors the wording follows the reference's fmt.Errorf strings).
+ *
+ * Threading: handles are independent and may be driven from different OS threads
+ * concurrently (cgo pins a goroutine to a thread for the duration of a call).  One handle
+ * must not be used from two threads at once, like the reference's goroutine-private
+ * pileupMutable (pileup.go:867-871).
+ */
+#ifndef BIO_PILEUP_H_
+#define BIO_PILEUP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One output row = what pm.w.Append(&PileupRow{...}) receives (pileup.go:524-557,
+ * row.go:48-66): Depth, then Counts[base][strand] for base in A,C,G,T,X and strand in +,-. */
+#define BP_ROW_U32 11
+
+enum {
+  BP_OK = 0,
+  BP_EINVAL = -1,     /* bad argument / call order */
+  BP_EDEVICE = -2,    /* HIP runtime failure (message has the HIP error string) */
+  BP_ENOMEM = -3,
+  BP_EDATA = -4,      /* a record violates max-read-len / max-read-span / CIGAR / qual range
+                         (pileup.go:766-772, :355-359, qual.go:26) */
+  BP_EUNSORTED = -5   /* records not in (ref_id,pos) order */
+};
+
+/* strand_req values = pileup.StrandType (pileup/common.go:77-88) */
+enum { BP_STRAND_NONE = 0, BP_STRAND_FWD = 1, BP_STRAND_REV = 2 };
+
+/* Options that reach the hot loop: pileupSNPOpts (pileup.go:597-622) fields read by
+ * processShard plus pileupContext (pileup.go:212-220) plus pileupShardContext.strandReq. */
+typedef struct bp_opts {
+  int32_t clip;          /* -clip            pileup_support.go:47-69 */
+  int32_t flag_exclude;  /* -flag-exclude    pileup.go:691 */
+  int32_t mapq;          /* -mapq            pileup.go:691 */
+  int32_t max_read_len;  /* -max-read-len    pileup.go:766 */
+  int32_t max_read_span; /* -max-read-span   pileup.go:769 */
+  int32_t min_base_qual; /* -min-base-qual   pileup.go:228, qual.go:62 */
+  int32_t stitch;        /* -stitch          pileup.go:788 */
+  int32_t ignore_strand; /* format is tsv/tsv-bgz (pileup.go:887): all counts in slot 0,
+                            StrandNone reads kept */
+  int32_t strand_req;    /* -per-strand pass (pileup.go:718-723); BP_STRAND_NONE otherwise */
+  int32_t device;        /* HIP device ordinal */
+  int32_t reserved[6];   /* must be 0 */
+} bp_opts;
+
+/* A run of decoded alignment records in coordinate order, as the reference's
+ * bamprovider.Iterator yields them (encoding/bamprovider/provider.go:141-166).  Field
+ * meaning = BAM fixed block as decoded by gbam.Unmarshal (encoding/bam/unmarshal.go:126-224).
+ * Structure-of-arrays; every pointer is caller-owned host memory and is copied before the
+ * call returns (the Go side recycles records with sam.PutInFreePool, pileup.go:805-807).
+ * Record i owns cigar[cigar_off[i] .. cigar_off[i]+n_cigar[i]), ceil(l_seq[i]/2) packed
+ * 4-bit bases at seq+seq_off[i] (BAM layout: first base in the high nibble), l_seq[i]
+ * quality bytes at qual+qual_off[i], and name bytes [name_off[i], name_off[i+1]).
+ * name/name_off may be NULL unless opts.stitch is set (names key the mate table,
+ * firstread.go:135-152). */
+typedef struct bp_record_batch {
+  int64_t n;
+  const int32_t* ref_id;
+  const int32_t* pos;
+  const int32_t* mate_ref_id;
+  const int32_t* mate_pos;
+  const uint16_t* flags;
+  const uint8_t* mapq;
+  const uint32_t* n_cigar;
+  const uint32_t* l_seq;
+  const uint64_t* cigar_off; /* in uint32 ops */
+  const uint32_t* cigar;     /* len<<4 | op, op codes MIDNSHP=X = 0..8 */
+  const uint64_t* seq_off;   /* bytes */
+  const uint8_t* seq;
+  const uint64_t* qual_off;  /* bytes */
+  const uint8_t* qual;
+  const uint64_t* name_off;  /* n+1 entries, bytes; may be NULL */
+  const uint8_t* name;       /* may be NULL */
+} bp_record_batch;
+
+typedef struct bp_handle bp_handle;
+
+/* Timing of the last bp_finish()/bp_compute(), from HIP events on the handle's stream. */
+typedef struct bp_timing {
+  float plan_ms;     /* window planning kernels */
+  float pileup_ms;   /* the pileup (count + flush) kernel */
+  float total_ms;    /* first launch to last completion */
+  int64_t n_windows;
+  int64_t n_items;   /* work items launched (windows x slices) */
+} bp_timing;
+
+/* Library/runtime probe.  Fails (BP_EDEVICE) when no HIP device is usable: there is no
+ * CPU fallback in this library. */
+int bp_init(int32_t device);
+
+/* newPileupMutable + pileupContext set-up for one job (pileup.go:189-209, :885-892).
+ * ref_len[n_ref] = header reference lengths (sam.Header.Refs()). */
+int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, bp_handle** out);
+
+/* pCtx.bedPart for this job (pileup.go:896-909): the sorted endpoint array of one
+ * reference as returned by BEDUnion.Subset(...).EndpointsByID(ref_id)
+ * (interval/bedunion.go:326-328, :753-852): 2N ints, interval k = [e[2k], e[2k+1]).
+ * Must be called before the first bp_submit; references never set have no positions. */
+int bp_set_bed(bp_handle* h, int32_t ref_id, const int32_t* endpoints, int32_t n_endpoints);
+
+/* The body of the iter.Scan() loop of processShard (pileup.go:671-808) for a run of
+ * records.  Records must continue the (ref_id,pos) order of earlier submits; the caller is
+ * responsible for the shard iterator semantics (padding, de-duplication of the overlap,
+ * pileup.go:673-689).  Copies the batch into pinned staging and starts the H2D copy. */
+int bp_submit(bp_handle* h, const bp_record_batch* batch);
+
+/* finishRef + w.Finish (pileup.go:624-639, :934-938): no more records; computes every
+ * row.  Blocks until the rows are resident on the device. */
+int bp_finish(bp_handle* h);
+
+/* Re-run the device computation on the already-resident records (what bp_finish runs),
+ * for measurement and for callers that change nothing but want fresh rows. */
+int bp_compute(bp_handle* h);
+
+/* Number of rows = number of BED positions of the job (one PileupRow per position,
+ * zero-depth ones included: pileup.go:518-570, pileup_support.go:89-123). */
+int64_t bp_num_rows(const bp_handle* h);
+
+/* Copy rows [first, first+n) to host, in ascending (ref_id,pos) order.  Any of ref_id,
+ * pos, vals may be NULL.  vals receives n*BP_ROW_U32 uint32. */
+int bp_rows(bp_handle* h, int64_t first, int64_t n, int32_t* ref_id, int32_t* pos, uint32_t* vals);
+
+/* Device pointer to the row values (num_rows*BP_ROW_U32 uint32, valid until bp_destroy or
+ * the next bp_compute) for consumers that keep working on the GPU. */
+int bp_rows_device(bp_handle* h, const uint32_t** dptr);
+
+/* Sum over all rows of each of the BP_ROW_U32 columns (uint64 each), reduced on device.
+ * Size-independent parity check: sums[0] = total depth. */
+int bp_column_sums(bp_handle* h, uint64_t sums[BP_ROW_U32]);
+
+int bp_get_timing(const bp_handle* h, bp_timing* out);
+
+/* Algorithmic bytes of the resident job per SURVEY.md section 8(d):
+ * sum_reads(32 + 4*n_cigar + ceil(l_seq/2) + l_seq) + 44*rows. */
+int64_t bp_algorithmic_bytes(const bp_handle* h);
+
+const char* bp_last_error(const bp_handle* h); /* h may be NULL: last create/init error */
+void bp_destroy(bp_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIO_PILEUP_H_ */

@@ -1,0 +1,157 @@
+"""ctypes wrapper around oracle/_build/liboracle.so (the CPU checker; test infrastructure).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from bio_amd._abi import BP_ROW_U32, bp_opts, bp_record_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+
+class orc_shard(C.Structure):
+    _fields_ = [("start_ref", C.c_int32), ("end_ref", C.c_int32), ("start", C.c_int32),
+                ("end", C.c_int32), ("padding", C.c_int32)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        build()
+    lib = C.CDLL(LIB)
+    i32p, u32p, u64p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    lib.orc_pileup.argtypes = [C.POINTER(bp_opts), C.c_int32, i32p, u64p, i32p,
+                               C.POINTER(bp_record_batch), C.c_int32, C.POINTER(orc_shard),
+                               C.c_int32, C.c_int64, i32p, i32p, u32p, C.POINTER(C.c_int64),
+                               C.c_char_p, C.c_int32]
+    lib.orc_pileup.restype = C.c_int
+    lib.orc_position_shards.argtypes = [C.c_int32, i32p, C.c_int32, C.c_int32,
+                                        C.POINTER(orc_shard), C.c_int32]
+    lib.orc_position_shards.restype = C.c_int32
+    lib.orc_align_relevant_bases.argtypes = [i32p, C.c_int32, C.c_int32, u32p, C.c_int32,
+                                             C.c_int32, i32p, i32p]
+    lib.orc_align_relevant_bases.restype = C.c_int
+    lib.orc_qual_pass.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.orc_qual_pass.restype = C.c_int
+    lib.orc_qual_sum.argtypes = [C.c_int, C.c_int]
+    lib.orc_qual_sum.restype = C.c_int
+    lib.orc_qual_round_margin.restype = C.c_double
+    lib.orc_get_strand.argtypes = [C.c_int32, C.c_int32, C.c_uint16]
+    lib.orc_get_strand.restype = C.c_int
+    lib.orc_next_exp2.argtypes = [C.c_int32]
+    lib.orc_next_exp2.restype = C.c_int32
+    lib.orc_unpack_seq.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_uint32]
+    lib.orc_unpack_seq.restype = None
+    lib.orc_murmur3_32.argtypes = [C.c_char_p, C.c_size_t]
+    lib.orc_murmur3_32.restype = C.c_uint32
+    lib.orc_shard_pad_start.argtypes = [C.c_int32, C.c_int32]
+    lib.orc_shard_pad_start.restype = C.c_int32
+    lib.orc_shard_pad_end.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.orc_shard_pad_end.restype = C.c_int32
+    lib.orc_bed_subset1.argtypes = [i32p, C.c_int32, C.c_int32, C.c_int32, i32p, C.c_int32]
+    lib.orc_bed_subset1.restype = C.c_int32
+    lib.orc_bed_intersects1.argtypes = [i32p, C.c_int32, C.c_int32, C.c_int32]
+    lib.orc_bed_intersects1.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def make_opts(**kw):
+    """bp_opts with the reference's DefaultOpts (pileup/snp/pileup.go:56-68)."""
+    o = bp_opts()
+    o.clip = 0
+    o.flag_exclude = 0xF00
+    o.mapq = 60
+    o.max_read_len = 500
+    o.max_read_span = 511
+    o.min_base_qual = 0
+    o.stitch = 0
+    o.ignore_strand = 0
+    o.strand_req = 0
+    o.device = 0
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, int(v))
+    return o
+
+
+def bed_arrays(n_ref, bed):
+    """bed: {ref_id: [[start,end],...] sorted disjoint} -> (bed_off u64[n_ref+1], bed_ep i32)."""
+    off = np.zeros(n_ref + 1, np.uint64)
+    eps = []
+    for r in range(n_ref):
+        iv = bed.get(r, [])
+        for s, e in iv:
+            eps += [s, e]
+        off[r + 1] = len(eps)
+    return off, np.array(eps, np.int32) if eps else np.zeros(0, np.int32)
+
+
+def n_bed_positions(bed):
+    return sum(e - s for iv in bed.values() for s, e in iv)
+
+
+def position_shards(ref_len, shard_size=100000, padding=511):
+    lib = load()
+    rl = np.ascontiguousarray(ref_len, np.int32)
+    n = lib.orc_position_shards(len(rl), rl.ctypes.data_as(C.POINTER(C.c_int32)), shard_size,
+                                padding, None, 0)
+    arr = (orc_shard * max(n, 1))()
+    lib.orc_position_shards(len(rl), rl.ctypes.data_as(C.POINTER(C.c_int32)), shard_size, padding,
+                            arr, n)
+    return arr, n
+
+
+def region_shard(ref_id, start0, end):
+    """The single unpadded shard of -region mode (pileup.go:1091-1097)."""
+    arr = (orc_shard * 1)()
+    arr[0] = orc_shard(ref_id, ref_id, start0, end, 0)
+    return arr, 1
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def pileup(opts, ref_len, bed, batch, shards=None, n_shards=None, parallelism=1):
+    """Run the oracle.  bed = {ref_id: [[s,e],...]}.  shards default to the -bed mode
+    100-kb position shards with Padding = max_read_span (pileup.go:1073-1084).
+    Returns (ref_id[P], pos[P], vals[P,11])."""
+    lib = load()
+    rl = np.ascontiguousarray(ref_len, np.int32)
+    n_ref = len(rl)
+    if shards is None:
+        shards, n_shards = position_shards(rl, 100000, opts.max_read_span)
+    off, ep = bed_arrays(n_ref, bed)
+    cap = n_bed_positions(bed) + 1
+    out_ref = np.zeros(cap, np.int32)
+    out_pos = np.zeros(cap, np.int32)
+    out_vals = np.zeros((cap, BP_ROW_U32), np.uint32)
+    n_rows = C.c_int64(0)
+    err = C.create_string_buffer(512)
+    cb = batch.as_c()
+    i32p, u32p, u64p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    rc = lib.orc_pileup(C.byref(opts), n_ref, rl.ctypes.data_as(i32p), off.ctypes.data_as(u64p),
+                        ep.ctypes.data_as(i32p), C.byref(cb), n_shards, shards, parallelism, cap,
+                        out_ref.ctypes.data_as(i32p), out_pos.ctypes.data_as(i32p),
+                        out_vals.ctypes.data_as(u32p), C.byref(n_rows), err, 512)
+    if rc != 0:
+        raise OracleError(err.value.decode())
+    n = n_rows.value
+    return out_ref[:n], out_pos[:n], out_vals[:n]

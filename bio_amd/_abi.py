@@ -60,7 +60,7 @@ class bp_timing(C.Structure):
 
 
 EXPORTS = [
-    "bp_init", "bp_create", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute",
+    "bp_init", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute",
     "bp_num_rows", "bp_rows", "bp_rows_device", "bp_column_sums", "bp_get_timing",
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
 ]
@@ -81,8 +81,11 @@ def load():
     H = C.c_void_p
     lib.bp_init.argtypes = [C.c_int32]
     lib.bp_init.restype = C.c_int
-    lib.bp_create.argtypes = [C.POINTER(bp_opts), C.c_int32, C.POINTER(C.c_int32), C.POINTER(H)]
+    lib.bp_create.argtypes = [C.POINTER(bp_opts), C.c_int32, C.POINTER(C.c_int32),
+                              C.POINTER(C.c_char_p), C.POINTER(H)]
     lib.bp_create.restype = C.c_int
+    lib.bp_reserve.argtypes = [H, C.c_int64, C.c_int64]
+    lib.bp_reserve.restype = C.c_int
     lib.bp_set_bed.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
     lib.bp_set_bed.restype = C.c_int
     lib.bp_submit.argtypes = [H, C.POINTER(bp_record_batch)]

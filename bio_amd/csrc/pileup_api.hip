@@ -1,0 +1,785 @@
+// pileup_api.hip -- host side of libbiopileup.so: the C ABI of include/bio_pileup.h.
+//
+// One bp_handle = one job of pileupSNPMain (pileup/snp/pileup.go:862-939).  Records are
+// packed into the device layout (pileup_device.h) in pinned staging buffers and streamed to
+// HBM with hipMemcpyAsync; the whole job stays resident (13 GB of records + 11 GB of rows for
+// a 30x chr1, against 288 GB of HBM3E) and bp_finish launches plan + pileup kernels over
+// every BED window.
+//
+// Host-side work that the reference also does per record before counting:
+//   * data errors (pileup.go:766-772, :355-359) are raised from bp_submit, in record order;
+//   * stitch mode: the mate table (firstread.go:176-204) is resolved here, because it is
+//     keyed by read name; the kernel receives one MateRef per record.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bio_pileup.h"
+#include "pileup_device.h"
+
+namespace bp {
+void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s);
+void launch_pileup(const KernelParams& P, hipStream_t s);
+void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s);
+int window_size();
+}  // namespace bp
+
+using namespace bp;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Staging {
+  ReadCore* cores = nullptr;
+  uint8_t* blob = nullptr;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+};
+
+constexpr size_t kStageReads = 1u << 20;       // records per staging slice
+constexpr size_t kStageBlob = 256u << 20;      // payload bytes per staging slice
+
+struct StoredRead {  // an entry of the firstread table (firstread.go:52-57)
+  std::string name;
+  int32_t pos;
+  int64_t idx;
+};
+
+}  // namespace
+
+struct bp_handle {
+  bp_opts o{};
+  int device = 0;
+  std::vector<int32_t> ref_len;
+  std::vector<std::string> ref_name;
+  std::vector<std::vector<int32_t>> bed;  // per reference endpoint arrays
+  bool frozen = false;                    // BED fixed, windows built
+  bool finished = false;
+  std::string err;
+
+  // flattened intervals + windows
+  std::vector<int32_t> iv_ref, iv_start, iv_end;
+  std::vector<int64_t> iv_row;  // n_iv + 1
+  std::vector<Window> windows;
+  int64_t n_rows = 0;
+
+  // record bookkeeping
+  int64_t n_reads = 0;
+  uint64_t blob_used = 0;  // in 8-byte units
+  int64_t algo_in_bytes = 0;
+  uint64_t last_key = 0;
+  int32_t max_span = 1;
+
+  // stitch: host mate table
+  std::vector<MateRef> mate;                          // per record
+  std::map<int32_t, std::vector<StoredRead>> stored;  // key: position the mate must start at
+  int32_t stored_ref = -1;
+  uint8_t qthr[96];
+
+  // device
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
+      d_err, d_sums, d_qthr;
+  Staging stage[2];
+  int cur_stage = 0;
+  bp_timing timing{};
+  bool rows_valid = false;
+};
+
+namespace {
+
+int fail(bp_handle* h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(h, e_ == hipErrorOutOfMemory ? BP_ENOMEM : BP_EDEVICE, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                  \
+  } while (0)
+
+// Grow a device buffer keeping its first `keep` bytes.
+int ensure(bp_handle* h, DevBuf& b, size_t need, size_t keep) {
+  if (need <= b.cap) return 0;
+  size_t cap = std::max(need, b.cap + b.cap / 2);
+  cap = (cap + 255) & ~(size_t)255;
+  void* np = nullptr;
+  HIP_TRY(h, hipMalloc(&np, cap));
+  if (b.p && keep) {
+    HIP_TRY(h, hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if (b.p) (void)hipFree(b.p);
+  b.p = np;
+  b.cap = cap;
+  return 0;
+}
+
+inline uint64_t sort_key(int32_t ref, int32_t pos) {
+  return ((uint64_t)(uint32_t)ref << 32) | (uint32_t)pos;
+}
+
+// pileup.GetStrand (pileup/common.go:94-114)
+inline int strand_of(int32_t ref, int32_t mate_ref, uint32_t flags) {
+  if (ref != mate_ref) return 0;
+  uint32_t f = flags & 0xf0u;
+  if (f == 0x60u || f == 0x90u) return 1;
+  if (f == 0x50u || f == 0xa0u) return 2;
+  if (flags & 0x8u) {
+    f &= 0x30u;
+    if (f == 0) return 1;
+    if (f == 0x30u) return 2;
+  }
+  return 0;
+}
+
+// BEDUnion.IntersectsByID (interval/bedunion.go:219-254)
+inline bool bed_intersects(const std::vector<int32_t>& e, int32_t start, int32_t limit) {
+  if (e.empty()) return false;
+  size_t idx = (size_t)(std::lower_bound(e.begin(), e.end(), start + 1) - e.begin());
+  if (idx & 1) return true;
+  return idx < e.size() && e[idx] < limit;
+}
+
+// End of the last BED interval overlapping [start, limit); requires bed_intersects.
+inline int32_t bed_last_overlap_end(const std::vector<int32_t>& e, int32_t limit) {
+  size_t re = ((size_t)(std::lower_bound(e.begin(), e.end(), limit) - e.begin()) + 1) & ~(size_t)1;
+  return e[re - 1];
+}
+
+// qualSumTable (pileup/snp/qual.go:35-58) -> per-row pass threshold.  The table is
+// nondecreasing along rows and columns (checked), so "qualSum[q0][q1] >= minBaseQual" is
+// "q1 >= thr[q0]".
+int build_qthr(bp_handle* h) {
+  static const double ln10 = 2.30258509299404568401799145468436421;
+  static const double log10e = 0.43429448190325182765112891891660508;
+  double ep[96];
+  uint8_t t[96][96];
+  for (int i = 0; i < 96; i++) ep[i] = std::exp((double)i * (-0.1 * ln10));
+  for (int i = 0; i < 96; i++)
+    for (int j = 0; j <= i; j++) {
+      double prod = ep[i] * ep[j];
+      double np = prod / ((1.0 - ep[i]) * (1.0 - ep[j]) + prod);
+      double r = std::round(std::log(np) * (-10.0 * log10e));
+      int q = (int)r;
+      if (q < 0) q = 0;
+      if (q > 95) q = 95;
+      t[i][j] = t[j][i] = (uint8_t)q;
+    }
+  for (int i = 0; i < 96; i++) {
+    int thr = 255;
+    for (int j = 95; j >= 0; j--) {
+      if (t[i][j] >= h->o.min_base_qual) thr = j;
+      else break;
+    }
+    for (int j = 0; j < 96; j++)
+      if ((t[i][j] >= h->o.min_base_qual) != (j >= thr))
+        return fail(h, BP_EINVAL, "qualSumTable row %d is not monotone", i);
+    h->qthr[i] = (uint8_t)thr;
+  }
+  return 0;
+}
+
+// Build flattened intervals and windows from the per-reference endpoint arrays.
+int freeze_bed(bp_handle* h) {
+  if (h->frozen) return 0;
+  const int W = window_size();
+  h->iv_ref.clear(); h->iv_start.clear(); h->iv_end.clear(); h->iv_row.clear();
+  h->windows.clear();
+  int64_t row = 0;
+  for (size_t r = 0; r < h->bed.size(); r++) {
+    const std::vector<int32_t>& e = h->bed[r];
+    for (size_t k = 0; k + 1 < e.size(); k += 2) {
+      if (e[k + 1] <= e[k]) continue;  // empty interval (Subset can emit [x,x))
+      h->iv_ref.push_back((int32_t)r);
+      h->iv_start.push_back(e[k]);
+      h->iv_end.push_back(e[k + 1]);
+      h->iv_row.push_back(row);
+      row += (int64_t)e[k + 1] - e[k];
+    }
+  }
+  h->iv_row.push_back(row);
+  h->n_rows = row;
+  const size_t n_iv = h->iv_start.size();
+  size_t k = 0;
+  while (k < n_iv) {
+    // a window starts at the first not-yet-covered BED position
+    int32_t ref = h->iv_ref[k];
+    int64_t cur = h->iv_start[k];
+    while (k < n_iv && h->iv_ref[k] == ref) {
+      Window w{};
+      w.ref_id = ref;
+      w.g0 = (int32_t)cur;
+      int64_t lim = cur + W;
+      w.iv_lo = (uint32_t)k;
+      w.row_base = h->iv_row[k] + (cur - h->iv_start[k]);
+      int64_t g1 = cur;
+      int64_t rows = 0;
+      size_t j = k;
+      while (j < n_iv && h->iv_ref[j] == ref && h->iv_start[j] < lim) {
+        int64_t s = std::max<int64_t>(h->iv_start[j], cur);
+        int64_t e2 = std::min<int64_t>(h->iv_end[j], lim);
+        rows += e2 - s;
+        g1 = e2;
+        if (h->iv_end[j] > lim) break;  // interval continues into the next window
+        j++;
+      }
+      w.g1 = (int32_t)g1;
+      w.n_rows = (int32_t)rows;
+      bool cont = (j < n_iv && h->iv_ref[j] == ref && h->iv_start[j] < lim && h->iv_end[j] > lim);
+      w.iv_hi = (uint32_t)(cont ? j + 1 : j);
+      w.full = (w.iv_hi - w.iv_lo == 1) ? 1 : 0;
+      h->windows.push_back(w);
+      if (cont) {
+        k = j;
+        cur = lim;
+      } else {
+        k = j;
+        if (k < n_iv && h->iv_ref[k] == ref) cur = h->iv_start[k];
+      }
+    }
+  }
+  // upload
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+    if (int rc = ensure(h, b, std::max<size_t>(bytes, 256), 0)) return rc;
+    if (bytes) HIP_TRY(h, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return 0;
+  };
+  if (int rc = up(h->d_windows, h->windows.data(), h->windows.size() * sizeof(Window))) return rc;
+  if (int rc = up(h->d_iv_start, h->iv_start.data(), n_iv * 4)) return rc;
+  if (int rc = up(h->d_iv_end, h->iv_end.data(), n_iv * 4)) return rc;
+  if (int rc = up(h->d_iv_row, h->iv_row.data(), (n_iv + 1) * 8)) return rc;
+  if (int rc = ensure(h, h->d_r0, std::max<size_t>(h->windows.size() * 4, 256), 0)) return rc;
+  if (int rc = ensure(h, h->d_r1, std::max<size_t>(h->windows.size() * 4, 256), 0)) return rc;
+  if (int rc = ensure(h, h->d_rows, std::max<size_t>((size_t)h->n_rows * 44, 256), 0)) return rc;
+  if (int rc = up(h->d_qthr, h->qthr, 96)) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->frozen = true;
+  return 0;
+}
+
+template <class F>
+void parallel_for(size_t n, int threads, F f) {
+  if (threads <= 1 || n < 2) {
+    for (size_t i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::atomic<size_t> next(0);
+  std::vector<std::thread> ts;
+  for (int t = 0; t < threads; t++)
+    ts.emplace_back([&] {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= n) break;
+        f(i);
+      }
+    });
+  for (auto& t : ts) t.join();
+}
+
+int pack_threads() {
+  unsigned hc = std::thread::hardware_concurrency();
+  int t = (int)std::min<unsigned>(hc ? hc : 1, 16);
+  return std::max(t, 1);
+}
+
+inline int32_t cigar_span(const uint32_t* c, uint32_t n, bool* simple, bool* has_bad) {
+  int64_t span = 0;
+  bool bad = false;
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t op = c[k] & 15u, len = c[k] >> 4;
+    // sam.Cigar.Lengths(): M, D, N, =, X consume the reference
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += len;
+    if (op > 5) bad = true;
+  }
+  *simple = (n == 1 && (c[0] & 15u) == 0);
+  *has_bad = bad;
+  return span > 0x7fffffff ? 0x7fffffff : (int32_t)span;
+}
+
+std::string read_name(const bp_record_batch* b, int64_t i) {
+  if (!b->name || !b->name_off) return std::string();
+  return std::string((const char*)b->name + b->name_off[i], (size_t)(b->name_off[i + 1] - b->name_off[i]));
+}
+
+const char* ref_label(bp_handle* h, int32_t ref, char* tmp, size_t n) {
+  if (ref >= 0 && (size_t)ref < h->ref_name.size() && !h->ref_name[(size_t)ref].empty())
+    return h->ref_name[(size_t)ref].c_str();
+  snprintf(tmp, n, "ref%d", ref);
+  return tmp;
+}
+
+// Per-record host pass over a slice: order check, data errors, span, stitch pairing.
+// Fills spans/simple for the packer.  Serial: it carries the mate table.
+int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1,
+               std::vector<int32_t>& spans, std::vector<uint8_t>& simple) {
+  const bp_opts& o = h->o;
+  for (int64_t i = i0; i < i1; i++) {
+    const int32_t ref = b->ref_id[i], pos = b->pos[i];
+    const uint64_t key = sort_key(ref, pos);
+    if (key < h->last_key)
+      return fail(h, BP_EUNSORTED, "bp_submit: record %lld (ref %d pos %d) is out of coordinate order",
+                  (long long)(h->n_reads + (i - i0)), ref, pos);
+    h->last_key = key;
+    const uint32_t n_cigar = b->n_cigar[i];
+    if (n_cigar > 0xffffu)
+      return fail(h, BP_EINVAL, "bp_submit: record with %u CIGAR ops (limit 65535)", n_cigar);
+    const uint32_t* cg = b->cigar + b->cigar_off[i];
+    bool simp = false, has_bad = false;
+    const int32_t span = cigar_span(cg, n_cigar, &simp, &has_bad);
+    spans[(size_t)(i - i0)] = span;
+    simple[(size_t)(i - i0)] = simp ? 1 : 0;
+    const int64_t gidx = h->n_reads + (i - i0);
+    if (o.stitch) h->mate[(size_t)gidx] = -1;
+    // read-level filters (pileup.go:691, :717-729)
+    const uint32_t flags = b->flags[i];
+    if (((uint32_t)o.flag_exclude & flags) != 0 || o.mapq > (int32_t)b->mapq[i] || n_cigar == 0) continue;
+    if (ref < 0 || (size_t)ref >= h->ref_len.size()) continue;  // unmapped: never in a shard
+    const int strand = strand_of(ref, b->mate_ref_id[i], flags);
+    if (o.strand_req != BP_STRAND_NONE) {
+      if (strand != o.strand_req) continue;
+    } else if (strand == 0 && !o.ignore_strand) {
+      continue;
+    }
+    // ring-buffer sizing assumptions (pileup.go:766-772), checked before the BED test
+    char tmp[32];
+    if ((int64_t)b->l_seq[i] > (int64_t)o.max_read_len)
+      return fail(h, BP_EDATA,
+                  "pileupMutable.processShard: maxReadLen is %d, but read %s at %s:%d has length %u",
+                  o.max_read_len, read_name(b, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
+                  b->l_seq[i]);
+    if (span > o.max_read_span)
+      return fail(h, BP_EDATA,
+                  "pileupMutable.processShard: maxReadSpan is %d, but read %s at %s:%d has span %d",
+                  o.max_read_span, read_name(b, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
+                  span);
+    if (span > h->max_span) h->max_span = span;
+    const int32_t map_end = pos + span;
+    const std::vector<int32_t>& e = h->bed[(size_t)ref];
+    const bool hits = bed_intersects(e, pos, map_end);
+    if (!hits) continue;
+    if (has_bad) {
+      // alignRelevantBases (pileup.go:355-359) fails at the first op outside MIDNSH that its
+      // walk reaches, i.e. one starting before the end of the last overlapping interval.
+      const int32_t last_end = bed_last_overlap_end(e, map_end);
+      int32_t rp = pos;
+      for (uint32_t k = 0; k < n_cigar; k++) {
+        uint32_t op = cg[k] & 15u, len = cg[k] >> 4;
+        if (rp >= last_end) break;
+        if (op == 0 || op == 2 || op == 3) rp += (int32_t)len;
+        else if (op > 5)
+          return fail(h, BP_EDATA, "alignRelevantBases: unexpected CIGAR code %u%c (read %s at %s:%d)",
+                      len, "MIDNSHP=XB??????"[op], read_name(b, i).c_str(),
+                      ref_label(h, ref, tmp, sizeof tmp), pos);
+      }
+    }
+    if (!o.stitch) continue;
+    // firstreadSNPTable.addOrRemove (firstread.go:176-204)
+    if (h->stored_ref != ref) {
+      h->stored.clear();  // finishRef evicts every stored read as an orphan (pileup.go:626)
+      h->stored_ref = ref;
+    }
+    // entries whose mate position is behind us can never be matched again
+    while (!h->stored.empty() && h->stored.begin()->first < pos) h->stored.erase(h->stored.begin());
+    const int32_t mate_pos = b->mate_pos[i];
+    if (strand == 0 || mate_pos >= map_end || (int64_t)mate_pos + o.max_read_span <= (int64_t)pos)
+      continue;  // processed alone now
+    if (pos >= mate_pos) {
+      // tryRemove: stored read at mate_pos with the same name and MatePos == pos
+      auto it = h->stored.find(pos);
+      bool found = false;
+      if (it != h->stored.end()) {
+        const std::string nm = read_name(b, i);
+        std::vector<StoredRead>& v = it->second;
+        for (size_t k = 0; k < v.size(); k++) {
+          if (v[k].pos == mate_pos && v[k].name == nm) {
+            const int64_t a = v[k].idx;
+            if (gidx >= (1ll << 30))
+              return fail(h, BP_EINVAL, "bp_submit: stitch mode supports at most 2^30 records per job");
+            h->mate[(size_t)gidx] = (MateRef)((a << 1) | 1);
+            h->mate[(size_t)a] = (MateRef)(gidx << 1);
+            v.erase(v.begin() + (long)k);
+            found = true;
+            break;
+          }
+        }
+      }
+      if (found || pos != mate_pos) continue;
+    }
+    h->stored[mate_pos].push_back(StoredRead{read_name(b, i), pos, gidx});
+  }
+  return 0;
+}
+
+int acquire_stage(bp_handle* h, Staging** out) {
+  Staging& s = h->stage[h->cur_stage];
+  h->cur_stage ^= 1;
+  if (!s.cores) {
+    HIP_TRY(h, hipHostMalloc((void**)&s.cores, kStageReads * sizeof(ReadCore), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc((void**)&s.blob, kStageBlob, hipHostMallocDefault));
+    HIP_TRY(h, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  if (s.busy) {
+    HIP_TRY(h, hipEventSynchronize(s.done));
+    s.busy = false;
+  }
+  *out = &s;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bp_init(int32_t device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, BP_EDEVICE, "bp_init: no HIP device (%s); libbiopileup has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= n) return fail(nullptr, BP_EINVAL, "bp_init: device %d of %d", device, n);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BP_EDEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+  return BP_OK;
+}
+
+int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const char* const* ref_name,
+              bp_handle** out) {
+  if (!opts || !out || n_ref < 0 || (n_ref > 0 && !ref_len)) return fail(nullptr, BP_EINVAL, "bp_create: null argument");
+  *out = nullptr;
+  // Pileup() argument validation (pileup.go:975-988), newQualPassTable (qual.go:62-66)
+  if (opts->clip < 0 || opts->clip * 2 >= opts->max_read_len)
+    return fail(nullptr, BP_EINVAL, "Pileup: invalid clip= argument");
+  if (opts->max_read_len > opts->max_read_span)
+    return fail(nullptr, BP_EINVAL, "Pileup: max-read-len= argument cannot be larger than max-read-span= argument");
+  if (opts->min_base_qual >= 96 || opts->min_base_qual < 0)
+    return fail(nullptr, BP_EINVAL, "newQualPassTable: minBaseQual too large");
+  if (opts->max_read_span > 0xffff) return fail(nullptr, BP_EINVAL, "bp_create: max_read_span above 65535");
+  if (opts->strand_req < 0 || opts->strand_req > 2) return fail(nullptr, BP_EINVAL, "bp_create: strand_req");
+  if (int rc = bp_init(opts->device)) return rc;
+  bp_handle* h = new bp_handle();
+  h->o = *opts;
+  h->device = opts->device;
+  h->ref_len.assign(ref_len, ref_len + n_ref);
+  h->ref_name.resize((size_t)n_ref);
+  if (ref_name)
+    for (int i = 0; i < n_ref; i++)
+      if (ref_name[i]) h->ref_name[(size_t)i] = ref_name[i];
+  h->bed.resize((size_t)n_ref);
+  if (int rc = build_qthr(h)) { delete h; return rc; }
+  auto bail = [&](const char* what, hipError_t e) {
+    int rc = fail(nullptr, BP_EDEVICE, "%s: %s", what, hipGetErrorString(e));
+    delete h;
+    return rc;
+  };
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return bail("hipStreamCreate", e);
+  for (int i = 0; i < 3; i++) {
+    e = hipEventCreate(&h->ev[i]);
+    if (e != hipSuccess) return bail("hipEventCreate", e);
+  }
+  *out = h;
+  return BP_OK;
+}
+
+int bp_reserve(bp_handle* h, int64_t n_records, int64_t payload_bytes) {
+  if (!h || n_records < 0 || payload_bytes < 0) return fail(h, BP_EINVAL, "bp_reserve: bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  // payload grows by padding: cigar to even count, qual/seq to whole 8-base units
+  size_t blob = (size_t)payload_bytes + (size_t)n_records * 16 + 4096;
+  if (int rc = ensure(h, h->d_cores, (size_t)n_records * sizeof(ReadCore) + 256, (size_t)h->n_reads * sizeof(ReadCore))) return rc;
+  if (int rc = ensure(h, h->d_blob, blob, (size_t)h->blob_used * 8)) return rc;
+  return BP_OK;
+}
+
+int bp_set_bed(bp_handle* h, int32_t ref_id, const int32_t* endpoints, int32_t n_endpoints) {
+  if (!h) return fail(h, BP_EINVAL, "bp_set_bed: null handle");
+  if (h->frozen) return fail(h, BP_EINVAL, "bp_set_bed: called after the first bp_submit");
+  if (ref_id < 0 || (size_t)ref_id >= h->bed.size() || n_endpoints < 0 || (n_endpoints & 1) ||
+      (n_endpoints > 0 && !endpoints))
+    return fail(h, BP_EINVAL, "bp_set_bed: bad argument (ref %d, %d endpoints)", ref_id, n_endpoints);
+  for (int32_t k = 0; k + 1 < n_endpoints; k++)
+    if (endpoints[k] > endpoints[k + 1] || (endpoints[k] == endpoints[k + 1] && (k & 1)))
+      return fail(h, BP_EINVAL, "bp_set_bed: endpoints of ref %d are not sorted disjoint intervals", ref_id);
+  if (n_endpoints && endpoints[0] < 0) return fail(h, BP_EINVAL, "bp_set_bed: negative coordinate");
+  h->bed[(size_t)ref_id].assign(endpoints, endpoints + n_endpoints);
+  return BP_OK;
+}
+
+int bp_submit(bp_handle* h, const bp_record_batch* b) {
+  if (!h || !b) return fail(h, BP_EINVAL, "bp_submit: null argument");
+  if (h->finished) return fail(h, BP_EINVAL, "bp_submit: called after bp_finish");
+  if (b->n < 0) return fail(h, BP_EINVAL, "bp_submit: negative record count");
+  if (h->o.stitch && b->n > 0 && (!b->name || !b->name_off))
+    return fail(h, BP_EINVAL, "bp_submit: stitch mode needs read names (firstread.go:135-152)");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = freeze_bed(h)) return rc;
+  h->rows_valid = false;
+  const int nthreads = pack_threads();
+  std::vector<int32_t> spans;
+  std::vector<uint8_t> simple;
+  std::vector<uint64_t> boff;
+  int64_t i0 = 0;
+  while (i0 < b->n) {
+    // slice bounded by staging capacity
+    int64_t i1 = i0;
+    uint64_t bytes = 0;
+    boff.clear();
+    while (i1 < b->n && (size_t)(i1 - i0) < kStageReads) {
+      uint64_t bb = blob_bytes(b->n_cigar[i1], b->l_seq[i1]);
+      if (bb > kStageBlob) return fail(h, BP_EINVAL, "bp_submit: record payload of %llu bytes", (unsigned long long)bb);
+      if (bytes + bb > kStageBlob) break;
+      boff.push_back(bytes);
+      bytes += bb;
+      i1++;
+    }
+    const size_t ns = (size_t)(i1 - i0);
+    if ((uint64_t)h->blob_used + bytes / 8 > 0xffffffffull)
+      return fail(h, BP_ENOMEM, "bp_submit: more than 32 GiB of record payload in one job");
+    if (h->n_reads + (int64_t)ns > 0x7fffffff)
+      return fail(h, BP_ENOMEM, "bp_submit: more than 2^31-1 records in one job");
+    spans.assign(ns, 0);
+    simple.assign(ns, 0);
+    if (h->o.stitch) h->mate.resize((size_t)h->n_reads + ns, -1);
+    if (int rc = scan_slice(h, b, i0, i1, spans, simple)) return rc;
+    Staging* st = nullptr;
+    if (int rc = acquire_stage(h, &st)) return rc;
+    const uint32_t blob_base = (uint32_t)h->blob_used;
+    std::atomic<int64_t> algo(0);
+    const size_t chunk = 4096;
+    parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
+      int64_t local = 0;
+      for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
+        const int64_t i = i0 + (int64_t)k;
+        ReadCore& rc = st->cores[k];
+        const uint32_t n_cigar = b->n_cigar[i], l = b->l_seq[i];
+        rc.pos = b->pos[i];
+        rc.ref_id = b->ref_id[i];
+        rc.mate_pos = b->mate_pos[i];
+        rc.mate_ref_id = b->mate_ref_id[i];
+        rc.flags = b->flags[i];
+        rc.mapq = b->mapq[i];
+        rc.aux = simple[k] ? AUX_SIMPLE : 0;
+        rc.n_cigar = (uint16_t)n_cigar;
+        rc.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
+        rc.l_seq = l;
+        rc.blob = blob_base + (uint32_t)(boff[k] / 8);
+        uint8_t* d = st->blob + boff[k];
+        const uint32_t ncp = (n_cigar + 1) & ~1u;
+        memcpy(d, b->cigar + b->cigar_off[i], (size_t)n_cigar * 4);
+        if (ncp != n_cigar) memset(d + (size_t)n_cigar * 4, 0, 4);
+        d += (size_t)ncp * 4;
+        const uint32_t U = blob_units(l);
+        memcpy(d, b->qual + b->qual_off[i], l);
+        memset(d + l, 0, (size_t)U * 8 - l);
+        d += (size_t)U * 8;
+        const uint32_t sb = (l + 1) / 2;
+        memcpy(d, b->seq + b->seq_off[i], sb);
+        const uint64_t tail = blob_bytes(n_cigar, l) - (uint64_t)ncp * 4 - (uint64_t)U * 8 - sb;
+        memset(d + sb, 0, (size_t)tail);
+        local += 32 + 4 * (int64_t)n_cigar + (l + 1) / 2 + l;
+      }
+      algo.fetch_add(local);
+    });
+    h->algo_in_bytes += algo.load();
+    // device capacity, then async copies
+    if (int rc = ensure(h, h->d_cores, ((size_t)h->n_reads + ns) * sizeof(ReadCore), (size_t)h->n_reads * sizeof(ReadCore))) return rc;
+    if (int rc = ensure(h, h->d_blob, ((size_t)h->blob_used) * 8 + bytes + 64, (size_t)h->blob_used * 8)) return rc;
+    HIP_TRY(h, hipMemcpyAsync((ReadCore*)h->d_cores.p + h->n_reads, st->cores, ns * sizeof(ReadCore),
+                              hipMemcpyHostToDevice, h->stream));
+    if (bytes)
+      HIP_TRY(h, hipMemcpyAsync((uint8_t*)h->d_blob.p + (size_t)h->blob_used * 8, st->blob, bytes,
+                                hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipEventRecord(st->done, h->stream));
+    st->busy = true;
+    h->n_reads += (int64_t)ns;
+    h->blob_used += bytes / 8;
+    i0 = i1;
+  }
+  return BP_OK;
+}
+
+int bp_compute(bp_handle* h) {
+  if (!h) return fail(h, BP_EINVAL, "bp_compute: null handle");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = freeze_bed(h)) return rc;
+  if (h->o.stitch) {
+    const size_t bytes = (size_t)h->n_reads * sizeof(MateRef);
+    if (int rc = ensure(h, h->d_mate, std::max<size_t>(bytes, 256), 0)) return rc;
+    if (bytes) HIP_TRY(h, hipMemcpyAsync(h->d_mate.p, h->mate.data(), bytes, hipMemcpyHostToDevice, h->stream));
+  }
+  if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_cores, 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_blob, 256, 0)) return rc;
+  DeviceError init{0x7fffffff, ERR_NONE};
+  HIP_TRY(h, hipMemcpyAsync(h->d_err.p, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  KernelParams P{};
+  P.cores = (const ReadCore*)h->d_cores.p;
+  P.blob = (const uint8_t*)h->d_blob.p;
+  P.mate = h->o.stitch ? (const MateRef*)h->d_mate.p : nullptr;
+  P.windows = (const Window*)h->d_windows.p;
+  P.win_r0 = (const int32_t*)h->d_r0.p;
+  P.win_r1 = (const int32_t*)h->d_r1.p;
+  P.iv_start = (const int32_t*)h->d_iv_start.p;
+  P.iv_end = (const int32_t*)h->d_iv_end.p;
+  P.iv_row = (const int64_t*)h->d_iv_row.p;
+  P.rows = (uint32_t*)h->d_rows.p;
+  P.err = (DeviceError*)h->d_err.p;
+  P.qthr = (const uint8_t*)h->d_qthr.p;
+  P.n_reads = h->n_reads;
+  P.n_windows = (int32_t)h->windows.size();
+  P.max_span = h->max_span;
+  P.clip = h->o.clip;
+  P.flag_exclude = h->o.flag_exclude;
+  P.mapq = h->o.mapq;
+  P.min_base_qual = h->o.min_base_qual;
+  P.stitch = h->o.stitch;
+  P.ignore_strand = h->o.ignore_strand;
+  P.strand_req = h->o.strand_req;
+  HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+  launch_plan(P, (int32_t*)h->d_r0.p, (int32_t*)h->d_r1.p, h->stream);
+  HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+  launch_pileup(P, h->stream);
+  HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+  HIP_TRY(h, hipGetLastError());
+  DeviceError got{};
+  HIP_TRY(h, hipMemcpyAsync(&got, h->d_err.p, sizeof(got), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->timing = bp_timing{};
+  (void)hipEventElapsedTime(&h->timing.plan_ms, h->ev[0], h->ev[1]);
+  (void)hipEventElapsedTime(&h->timing.pileup_ms, h->ev[1], h->ev[2]);
+  (void)hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[2]);
+  h->timing.n_windows = (int64_t)h->windows.size();
+  h->timing.n_items = (int64_t)h->windows.size();
+  if (got.read != 0x7fffffff)
+    return fail(h, BP_EDATA,
+                "qualPassTable.lookup2: base quality >= 96 in a stitched overlap (record %d); the "
+                "reference panics with index out of range (qual.go:26,79-81)", got.read);
+  h->rows_valid = true;
+  return BP_OK;
+}
+
+int bp_finish(bp_handle* h) {
+  if (!h) return fail(h, BP_EINVAL, "bp_finish: null handle");
+  h->finished = true;
+  h->stored.clear();
+  return bp_compute(h);
+}
+
+int64_t bp_num_rows(const bp_handle* h) {
+  if (!h) return -1;
+  if (h->frozen) return h->n_rows;
+  int64_t n = 0;
+  for (const auto& e : h->bed)
+    for (size_t k = 0; k + 1 < e.size(); k += 2) n += (int64_t)e[k + 1] - e[k];
+  return n;
+}
+
+int bp_rows(bp_handle* h, int64_t first, int64_t n, int32_t* ref_id, int32_t* pos, uint32_t* vals) {
+  if (!h) return fail(h, BP_EINVAL, "bp_rows: null handle");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_rows: no computed rows (call bp_finish)");
+  if (first < 0 || n < 0 || first + n > h->n_rows) return fail(h, BP_EINVAL, "bp_rows: range [%lld,%lld) of %lld", (long long)first, (long long)(first + n), (long long)h->n_rows);
+  if (n == 0) return BP_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (vals)
+    HIP_TRY(h, hipMemcpy(vals, (const uint32_t*)h->d_rows.p + first * BP_ROW_U32, (size_t)n * 44, hipMemcpyDeviceToHost));
+  if (ref_id || pos) {
+    size_t k = (size_t)(std::upper_bound(h->iv_row.begin(), h->iv_row.end(), first) - h->iv_row.begin()) - 1;
+    int64_t done = 0;
+    while (done < n) {
+      int64_t r = first + done;
+      while (h->iv_row[k + 1] <= r) k++;
+      int64_t off = r - h->iv_row[k];
+      int64_t cnt = std::min<int64_t>(n - done, (int64_t)(h->iv_end[k] - h->iv_start[k]) - off);
+      for (int64_t t = 0; t < cnt; t++) {
+        if (ref_id) ref_id[done + t] = h->iv_ref[k];
+        if (pos) pos[done + t] = (int32_t)(h->iv_start[k] + off + t);
+      }
+      done += cnt;
+    }
+  }
+  return BP_OK;
+}
+
+int bp_rows_device(bp_handle* h, const uint32_t** dptr) {
+  if (!h || !dptr) return fail(h, BP_EINVAL, "bp_rows_device: null argument");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_rows_device: no computed rows");
+  *dptr = (const uint32_t*)h->d_rows.p;
+  return BP_OK;
+}
+
+int bp_column_sums(bp_handle* h, uint64_t sums[BP_ROW_U32]) {
+  if (!h || !sums) return fail(h, BP_EINVAL, "bp_column_sums: null argument");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_column_sums: no computed rows");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = ensure(h, h->d_sums, 256, 0)) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_sums.p, 0, 11 * 8, h->stream));
+  launch_column_sums((const uint32_t*)h->d_rows.p, h->n_rows, (unsigned long long*)h->d_sums.p, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(sums, h->d_sums.p, 11 * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return BP_OK;
+}
+
+int bp_get_timing(const bp_handle* h, bp_timing* out) {
+  if (!h || !out) return BP_EINVAL;
+  *out = h->timing;
+  return BP_OK;
+}
+
+int64_t bp_algorithmic_bytes(const bp_handle* h) {
+  if (!h) return -1;
+  return h->algo_in_bytes + 44 * bp_num_rows(h);
+}
+
+const char* bp_last_error(const bp_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+void bp_destroy(bp_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (DevBuf* b : {&h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+                    &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr})
+    b->release();
+  for (Staging& s : h->stage) {
+    if (s.cores) (void)hipHostFree(s.cores);
+    if (s.blob) (void)hipHostFree(s.blob);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  for (hipEvent_t e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// pileup_device.h -- data layout shared by the host code and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace bp {
+
+// One alignment record's fixed part, 32 bytes (same size as the BAM fixed block decoded at
+// encoding/bam/unmarshal.go:126-224).  `span` is the reference span sam.Cigar.Lengths()
+// returns (pileup.go:769), clamped to 0xffff; `aux` bit 0 = CIGAR is a single M op.
+struct ReadCore {
+  int32_t pos;
+  int32_t ref_id;
+  int32_t mate_pos;
+  int32_t mate_ref_id;
+  uint16_t flags;
+  uint8_t mapq;
+  uint8_t aux;
+  uint16_t n_cigar;
+  uint16_t span;
+  uint32_t l_seq;
+  uint32_t blob;  // offset of the record's payload in 8-byte units
+};
+static_assert(sizeof(ReadCore) == 32, "ReadCore must be 32 bytes");
+
+enum : uint8_t { AUX_SIMPLE = 1 };
+
+// Payload ("blob") of a record, 8-byte aligned:
+//   uint32 cigar[n_cigar rounded up to even]
+//   uint8  qual[8*U]      U = ceil(l_seq/8); pad bytes 0
+//   uint8  seq4[4*U]      BAM packed 4-bit bases; pad nibbles 0
+//   pad to 8 bytes
+inline uint32_t blob_units(uint32_t l_seq) { return (l_seq + 7) >> 3; }
+inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq) {
+  uint64_t u = blob_units(l_seq);
+  uint64_t b = (uint64_t)((n_cigar + 1) & ~1u) * 4 + 12 * u;
+  return (b + 7) & ~(uint64_t)7;
+}
+
+// A genomic window: at most W consecutive positions of one reference, covering BED
+// positions only at its ends; one workgroup accumulates it in LDS and flushes it.
+struct Window {
+  int32_t ref_id;
+  int32_t g0, g1;        // [g0, g1), g1 - g0 <= W
+  uint32_t iv_lo, iv_hi; // BED intervals (global index) intersecting the window
+  int32_t full;          // 1: [g0,g1) lies inside interval iv_lo
+  int32_t n_rows;        // BED positions in the window
+  int32_t pad;
+  int64_t row_base;      // output row of the first BED position in the window
+};
+static_assert(sizeof(Window) == 40, "Window must be 40 bytes");
+
+// mate table entry for stitch mode: -1 = processed alone, else (mate_index << 1) | second,
+// second = 1 for the read that found its mate in the table (readPair[0], firstread.go:187).
+typedef int32_t MateRef;
+
+struct DeviceError {
+  int32_t read;  // smallest record index with a data error, or 0x7fffffff
+  int32_t kind;
+};
+enum { ERR_NONE = 0, ERR_QUAL_RANGE = 1 };
+
+struct KernelParams {
+  const ReadCore* cores;
+  const uint8_t* blob;
+  const MateRef* mate;        // NULL unless stitch
+  const Window* windows;
+  const int32_t* win_r0;      // per window: first record that may overlap it
+  const int32_t* win_r1;      // per window: one past the last record starting before g1
+  const int32_t* iv_start;
+  const int32_t* iv_end;
+  const int64_t* iv_row;
+  uint32_t* rows;             // n_rows * 11
+  DeviceError* err;
+  const uint8_t* qthr;        // [96] stitch: qthr[q0] = smallest q1 with qualSum[q0][q1] >= minBaseQual (255: none)
+  int64_t n_reads;
+  int32_t n_windows;
+  int32_t max_span;           // largest (clamped) span among submitted records
+  // options (bp_opts)
+  int32_t clip, flag_exclude, mapq, min_base_qual, stitch, ignore_strand, strand_req;
+};
+
+}  // namespace bp

@@ -109,7 +109,12 @@ int bp_init(int32_t device);
 
 /* newPileupMutable + pileupContext set-up for one job (pileup.go:189-209, :885-892).
  * ref_len[n_ref] = header reference lengths (sam.Header.Refs()). */
-int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, bp_handle** out);
+int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len,
+              const char* const* ref_name /* may be NULL; used in error messages only */,
+              bp_handle** out);
+
+/* Optional capacity hint (records, payload bytes) so device buffers are sized once. */
+int bp_reserve(bp_handle* h, int64_t n_records, int64_t payload_bytes);
 
 /* pCtx.bedPart for this job (pileup.go:896-909): the sorted endpoint array of one
  * reference as returned by BEDUnion.Subset(...).EndpointsByID(ref_id)

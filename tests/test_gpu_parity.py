@@ -1,0 +1,234 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle (bit-exact)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from bio_amd import _abi, records as R, snp, synth
+from test_oracle_vs_naive import CASES, random_bed, random_records
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def device_rows(opts, ref_len, bed, batches):
+    return snp.run_job(opts, ref_len, bed, batches)
+
+
+def assert_same(got, want, what=""):
+    gr, gp, gv = got
+    wr, wp, wv = want
+    assert len(gp) == len(wp), (what, len(gp), len(wp))
+    assert (gr == wr).all() and (gp == wp).all(), what
+    bad = np.nonzero((gv != wv).any(axis=1))[0]
+    assert len(bad) == 0, (what, len(bad), [(int(wp[i]), gv[i].tolist(), wv[i].tolist()) for i in bad[:5]])
+
+
+def test_reference_kat_on_device():
+    """pileup/snp/pileup_test.go:56-315 through the device path."""
+    kat = json.load(open(os.path.join(GOLDEN, "pileup_kat.json")))
+    o = kat["opts"]
+    for case in kat["cases"]:
+        opts = O.make_opts(clip=o["clip"], flag_exclude=o["flag_exclude"], mapq=o["mapq"],
+                           max_read_len=o["max_read_len"], max_read_span=o["max_read_span"],
+                           min_base_qual=o["min_base_qual"], stitch=o["stitch"], ignore_strand=0)
+        batch = R.from_records([dict(r, ref_id=0, mate_ref_id=0) for r in case["reads"]])
+        ref, pos, vals = device_rows(opts, [kat["ref"]["len"]], {0: kat["bed"]}, [batch])
+        assert [int(p) for p in pos] == [w["pos"] for w in case["want"]]
+        for i, w in enumerate(case["want"]):
+            assert vals[i, 1:9].reshape(4, 2).tolist() == w["counts"], (case["name"], w["pos"])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_random_small_vs_oracle(seed, case):
+    rng = random.Random(1000 * case + seed)
+    kw = dict(CASES[case])
+    ref_len = 3000
+    batch = R.from_records(random_records(rng, 150, ref_len=ref_len, n_ref=2))
+    bed = random_bed(rng, ref_len, n_ref=2, dense=(seed % 2 == 0))
+    opts = O.make_opts(max_read_len=100, max_read_span=120, **kw)
+    want = O.pileup(opts, [ref_len, ref_len], bed, batch, parallelism=1)
+    got = device_rows(opts, [ref_len, ref_len], bed, [batch])
+    assert_same(got, want, f"case {case} seed {seed}")
+
+
+def test_split_submits_and_empty_inputs():
+    rng = random.Random(9)
+    ref_len = 5000
+    recs = random_records(rng, 400, ref_len=ref_len)
+    batch = R.from_records(recs)
+    bed = random_bed(rng, ref_len, dense=True)
+    for stitch in (0, 1):
+        opts = O.make_opts(max_read_len=100, max_read_span=120, stitch=stitch, min_base_qual=20)
+        want = O.pileup(opts, [ref_len], bed, batch)
+        parts = [batch.slice(0, 100), batch.slice(100, 101), batch.slice(101, 101),
+                 batch.slice(101, batch.n)]
+        assert_same(device_rows(opts, [ref_len], bed, parts), want, f"split stitch={stitch}")
+        # no records at all: one zero row per BED position
+        ref, pos, vals = device_rows(opts, [ref_len], bed, [])
+        assert len(pos) == O.n_bed_positions(bed) and vals.sum() == 0
+    # empty BED: no rows
+    ref, pos, vals = device_rows(O.make_opts(), [ref_len], {}, [batch])
+    assert len(pos) == 0
+
+
+def _synth_case(regions, bed, ref_len, opts, region_filter=None, **gen):
+    sb = synth.generate(regions, **gen)
+    rb = sb.to_record_batch()
+    if region_filter is not None:
+        ref, s, e = region_filter
+        lo = int(np.searchsorted(rb.pos, s, "left"))
+        hi = int(np.searchsorted(rb.pos, e, "left"))
+        shards, n = O.region_shard(ref, s, e)
+        want = O.pileup(opts, ref_len, bed, rb, shards=shards, n_shards=n)
+        got = device_rows(opts, ref_len, bed, [rb.slice(lo, hi)])
+    else:
+        want = O.pileup(opts, ref_len, bed, rb, parallelism=1)
+        got = device_rows(opts, ref_len, bed, [rb])
+    return got, want, sb
+
+
+@pytest.mark.parametrize("mode", ["basestrand", "tsv", "fwd", "rev", "stitch", "minq_clip"])
+def test_c1_shape_1mb_30x(mode):
+    """BASELINE config 1 shape: 1 Mb region at 30x, 2x150 reads, CIGAR/flag/MAPQ mix."""
+    kw = dict(basestrand=dict(), tsv=dict(ignore_strand=1),
+              fwd=dict(ignore_strand=1, strand_req=1), rev=dict(ignore_strand=1, strand_req=2),
+              stitch=dict(stitch=1, min_base_qual=20), minq_clip=dict(min_base_qual=13, clip=5))[mode]
+    opts = O.make_opts(**kw)
+    ref_len = [3_000_000]
+    bed = {0: [[1_000_000, 2_000_000]]}
+    got, want, sb = _synth_case([(0, 1_000_000, 2_000_000, 30.0)], bed, ref_len, opts,
+                                with_names=True)
+    assert_same(got, want, mode)
+    assert want[2][:, 0].sum() > 20e6  # the case is not vacuous
+
+
+def test_c1_region_mode_no_halo():
+    """-region semantics: a single unpadded shard (pileup.go:1091-1097)."""
+    opts = O.make_opts()
+    bed = {0: [[1_200_000, 1_300_000]]}
+    got, want, _ = _synth_case([(0, 1_000_000, 1_500_000, 30.0)], bed, [3_000_000], opts,
+                               region_filter=(0, 1_200_000, 1_300_000))
+    assert_same(got, want, "region")
+
+
+def test_c4_shape_deep_panel_stitched():
+    """BASELINE config 4 shape (scaled): 200-bp targets, deep, overlapping 2x150 mates."""
+    rng = random.Random(4)
+    targets, p = [], 10_000
+    for _ in range(12):
+        targets.append([p, p + 200])
+        p += 200 + rng.randint(50, 3000)
+    bed = {0: targets}
+    regions = [(0, s, e, 2000.0) for s, e in targets]
+    opts = O.make_opts(stitch=1, min_base_qual=20, mapq=60)
+    got, want, sb = _synth_case(regions, bed, [p + 10_000], opts, with_names=True,
+                                insert_mean=170.0, insert_sd=20.0, insert_min=100, insert_max=300)
+    assert_same(got, want, "panel")
+    assert want[2][:, 0].max() > 1000
+
+
+def test_snp_panel_many_tiny_intervals():
+    """1-bp targets like cmd/bio-pileup/testdata/common_chr2_subset.bed."""
+    rng = random.Random(11)
+    iv, p = [], 100_000
+    while p < 400_000:
+        iv.append([p, p + 1])
+        p += rng.randint(1, 120)
+    bed = {0: iv}
+    opts = O.make_opts(ignore_strand=1)
+    got, want, _ = _synth_case([(0, 100_000, 400_000, 20.0)], bed, [1_000_000], opts)
+    assert_same(got, want, "snp panel")
+
+
+def test_multi_reference_and_empty_contigs():
+    """Rows for contigs without reads and after the last read (pileup_support.go:112-123)."""
+    opts = O.make_opts()
+    ref_len = [500_000, 300_000, 400_000, 100_000]
+    bed = {0: [[100_000, 150_000]], 1: [[0, 1000]], 2: [[50_000, 60_000], [70_000, 70_500]],
+           3: [[99_000, 100_000]]}
+    got, want, _ = _synth_case([(0, 90_000, 160_000, 15.0), (2, 40_000, 80_000, 15.0)], bed, ref_len,
+                               opts)
+    assert_same(got, want, "multi-ref")
+
+
+def test_errors_match_reference_wording():
+    base = dict(name="x", ref_id=0, pos=100, mapq=60, flags=0x63, mate_pos=150)
+    opts = O.make_opts(max_read_len=20, max_read_span=30)
+    bed = {0: [[0, 1000]]}
+
+    def run(rec, bed=bed, opts=opts):
+        return device_rows(opts, [1000], bed, [R.from_records([rec])])
+
+    long_read = dict(base, cigar=[("M", 21)], seq="A" * 21, qual=[30] * 21)
+    with pytest.raises(snp.PileupError, match="maxReadLen is 20, but read x at"):
+        run(long_read)
+    wide = dict(base, cigar=[("M", 5), ("N", 26), ("M", 5)], seq="A" * 10, qual=[30] * 10)
+    with pytest.raises(snp.PileupError, match="maxReadSpan is 30"):
+        run(wide)
+    badop = dict(base, cigar=[("M", 5), ("=", 5)], seq="A" * 10, qual=[30] * 10)
+    with pytest.raises(snp.PileupError, match="unexpected CIGAR code"):
+        run(badop)
+    ref, pos, vals = run(badop, bed={0: [[100, 105]]})
+    assert vals[:, 0].tolist() == [1] * 5
+    ref, pos, vals = run(dict(long_read, mapq=3))
+    assert vals.sum() == 0
+    with pytest.raises(snp.PileupError, match="invalid clip"):
+        device_rows(O.make_opts(clip=250), [1000], bed, [])
+    with pytest.raises(snp.PileupError, match="max-read-len"):
+        device_rows(O.make_opts(max_read_len=600), [1000], bed, [])
+    with pytest.raises(snp.PileupError, match="minBaseQual too large"):
+        device_rows(O.make_opts(min_base_qual=96), [1000], bed, [])
+    # unsorted input
+    a = dict(base, cigar=[("M", 5)], seq="AAAAA", qual=[30] * 5)
+    with pytest.raises(snp.PileupError, match="out of coordinate order"):
+        device_rows(opts, [1000], bed, [R.from_records([a, dict(a, pos=50)])])
+    # stitched overlap with an out-of-range quality: Go panics, we return BP_EDATA
+    q = [30] * 5
+    p1 = dict(name="p", ref_id=0, pos=100, mapq=60, flags=0x63, mate_pos=102, cigar=[("M", 5)],
+              seq="AAAAA", qual=[30, 30, 30, 99, 30])
+    p2 = dict(name="p", ref_id=0, pos=102, mapq=60, flags=0x93, mate_pos=100, cigar=[("M", 5)],
+              seq="AAAAA", qual=q)
+    with pytest.raises(snp.PileupError, match="index out of range"):
+        device_rows(O.make_opts(stitch=1), [1000], bed, [R.from_records([p1, p2])])
+    with pytest.raises(O.OracleError, match="index out of range"):
+        O.pileup(O.make_opts(stitch=1), [1000], bed, R.from_records([p1, p2]))
+
+
+def test_checksum_properties_at_scale():
+    """Size-independent properties on a larger case (20 Mb at 30x): column sums from the
+    device equal sums over rows, depth equals the kept aligned bases, strand split adds up."""
+    L = 20_000_000
+    sb = synth.generate([(0, 0, L, 30.0)], frac_softclip=0, frac_del=0, frac_ins=0, frac_hardclip=0,
+                        frac_low_mapq=0, frac_dup=0, frac_secondary=0, frac_mate_other_ref=0)
+    rb = sb.to_record_batch()
+    bed = {0: [[0, L + 1000]]}
+    opts = O.make_opts(ignore_strand=1)
+    with snp.PileupJob(opts, [L + 1000]) as job:
+        job.set_bed(bed)
+        job.submit(rb)
+        job.finish()
+        sums = job.column_sums()
+        # every read is plain 150M, unfiltered, inside the BED: depth = all aligned bases
+        assert sums[0] == sb.aligned_bases
+        assert sum(sums[1:]) == sums[0]  # min_base_qual 0: every base lands in a count slot
+        assert sums[2] == sums[4] == sums[6] == sums[8] == sums[10] == 0  # tsv: slot 0 only
+        ref, pos, vals = job.rows(5_000_000, 100_000)
+        assert (pos == np.arange(5_000_000, 5_100_000)).all()
+        # a window of rows against the oracle run on just the overlapping reads
+        lo = int(np.searchsorted(rb.pos, 5_000_000 - 600))
+        hi = int(np.searchsorted(rb.pos, 5_100_000))
+        wr, wp, wv = O.pileup(opts, [L + 1000], {0: [[5_000_000, 5_100_000]]}, rb.slice(lo, hi))
+        assert (vals == wv).all()
+    opts2 = O.make_opts(ignore_strand=0)
+    with snp.PileupJob(opts2, [L + 1000]) as job:
+        job.set_bed(bed)
+        job.submit(rb)
+        job.finish()
+        s2 = job.column_sums()
+        assert s2[0] == sums[0]
+        assert [s2[1 + 2 * b] + s2[2 + 2 * b] for b in range(5)] == [sums[1 + 2 * b] for b in range(5)]

@@ -104,7 +104,7 @@ def test_c1_shape_1mb_30x(mode):
     got, want, sb = _synth_case([(0, 1_000_000, 2_000_000, 30.0)], bed, ref_len, opts,
                                 with_names=True)
     assert_same(got, want, mode)
-    assert want[2][:, 0].sum() > 20e6  # the case is not vacuous
+    assert want[2][:, 0].sum() > 10e6  # the case is not vacuous
 
 
 def test_c1_region_mode_no_halo():
@@ -138,7 +138,7 @@ def test_snp_panel_many_tiny_intervals():
     iv, p = [], 100_000
     while p < 400_000:
         iv.append([p, p + 1])
-        p += rng.randint(1, 120)
+        p += rng.randint(2, 120)
     bed = {0: iv}
     opts = O.make_opts(ignore_strand=1)
     got, want, _ = _synth_case([(0, 100_000, 400_000, 20.0)], bed, [1_000_000], opts)

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned bases piled up per second on MI355X (BASELINE.json metric).
+
+A step = one pass of the pileup hot path (window planning + count/flush kernels, i.e.
+bp_compute) over one resident batch of synthetic coordinate-sorted records.
+
+Workload at N=1 (BASELINE.json configs[1]): synthetic 30x chr1 (248,956,422 bp), 2x150 FR
+pairs with the SURVEY.md section 8(d) CIGAR/flag/MAPQ mix, BED = whole contig, basestrand
+semantics (per-strand counts in one pass).  With --gpus N every rank processes its own
+chr1-sized contig (independent genomic partitions, no data-path collective): weak scaling.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHR1_LEN = 248_956_422
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def kept_aligned_bases(rb, opts_kw):
+    """B of SURVEY.md section 8(d), counted on the host from the generated records:
+    CIGAR-M bases of records passing the read-level filters (all of them lie on the BED)."""
+    flags = rb.flags.astype(np.uint32)
+    keep = ((flags & opts_kw["flag_exclude"]) == 0) & (rb.mapq >= opts_kw["mapq"]) & (rb.n_cigar > 0)
+    f = flags & 0xF0
+    same = rb.ref_id == rb.mate_ref_id
+    fwd = same & ((f == 0x60) | (f == 0x90) | (((flags & 8) != 0) & ((f & 0x30) == 0)))
+    rev = same & ((f == 0x50) | (f == 0xA0) | (((flags & 8) != 0) & ((f & 0x30) == 0x30)))
+    keep &= fwd | rev  # basestrand formats drop StrandNone (pileup.go:724-729)
+    ops = rb.cigar & 15
+    mlen = np.where(ops == 0, rb.cigar >> 4, 0).astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(mlen)])
+    off = rb.cigar_off.astype(np.int64)
+    per_read = csum[off + rb.n_cigar.astype(np.int64)] - csum[off]
+    return int(per_read[keep].sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--length", type=int, default=CHR1_LEN, help="contig length (default chr1)")
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--cpu-sample-mb", type=float, default=200.0,
+                    help="genomic megabases of the workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pileup path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bio_amd import _abi, snp, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+    L = args.length
+    opts_kw = dict(flag_exclude=0xF00, mapq=60)
+    o = snp.Opts()  # DefaultOpts
+    bopts = snp.device_opts(o, "basestrand-tsv", device=local_rank)
+
+    t0 = time.time()
+    threads = min(16, os.cpu_count() or 1)
+    # every rank gets its own contig (seed differs): partition = contig, as in config 3
+    sb = synth.generate([(0, 0, L - 1000, args.coverage)], seed=synth.SEED + rank, threads=threads)
+    rb = sb.to_record_batch()
+    gen_s = time.time() - t0
+    B = kept_aligned_bases(rb, opts_kw)
+
+    job = snp.PileupJob(bopts, [L], ["chr1"])
+    job.set_bed({0: [[0, L]]})
+    job.reserve(rb.n, len(rb.cigar) * 4 + len(rb.seq) + len(rb.qual))
+    t0 = time.time()
+    job.submit(rb)
+    torch.cuda.synchronize()
+    submit_s = time.time() - t0
+    host_bytes = rb.algorithmic_input_bytes()
+
+    for _ in range(args.warmup):
+        job.compute()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    plan_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.compute()
+        t = job.timing()
+        kernel_ms.append(t.pileup_ms)
+        plan_ms.append(t.plan_ms)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+        tb = torch.tensor([B], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_B = int(tb.item())
+    else:
+        total_B = B
+
+    # sanity outside the timed region: device depth sum == host-counted aligned bases
+    sums = job.column_sums()
+    if sums[0] != B:
+        raise SystemExit(f"device depth sum {sums[0]} != host aligned bases {B}")
+    algo_bytes = job.algorithmic_bytes()
+    n_rows = job.num_rows
+    tm = job.timing()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as O
+        sample_bp = int(min(args.cpu_sample_mb * 1e6, L))
+        hi = int(np.searchsorted(rb.pos, sample_bp, "left"))
+        sample = rb.slice(0, hi)
+        oopts = O.make_opts()
+        tc = time.perf_counter()
+        wr, wp, wv = O.pileup(oopts, [L], {0: [[0, sample_bp]]}, sample, parallelism=1)
+        cpu_s = time.perf_counter() - tc
+        cpu_B = int(wv[:, 0].sum())
+        # and it is a parity check too: same rows from the device
+        dr, dp, dv = job.rows(0, sample_bp - 600)
+        if not (dv == wv[:sample_bp - 600]).all():
+            raise SystemExit("device rows differ from the CPU oracle on the baseline sample")
+        cpu = {"value": round(cpu_B / cpu_s / 1e9, 4), "unit": "Gbase/s", "cores": 1, "kind": "port",
+               "sample": f"first {sample_bp / 1e6:.0f} Mb of the same workload ({hi} records, "
+                         f"{cpu_B} aligned bases) in {cpu_s:.1f} s, records in memory -> rows, "
+                         f"C restatement of the reference algorithm (oracle/pileup_oracle.c), 1 thread"}
+        del wr, wp, wv, dr, dp, dv
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        k_ms = float(np.mean(kernel_ms))
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "aligned bases piled up/sec",
+            "value": round(total_B / (elapsed / args.steps) / 1e9, 3),
+            "unit": "Gbase/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic {args.coverage:g}x chr1-sized contig ({L} bp) per GPU, 2x150 FR pairs, "
+                            "BED = whole contig, basestrand (per-strand) counts, DefaultOpts",
+                "records_per_gpu": rb.n, "aligned_bases_per_gpu": B, "bed_positions_per_gpu": n_rows,
+                "windows": int(tm.n_windows), "partitioning": f"contig per GPU x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "bp::pileup_kernel",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms_avg": round(k_ms, 4), "plan_ms_avg": round(float(np.mean(plan_ms)), 4),
+            },
+            "cpu_baseline": cpu,
+            "setup": {"generate_s": round(gen_s, 1), "pack_and_h2d_s": round(submit_s, 2),
+                      "h2d_inclusive_Gbase_per_s": round(B / (submit_s + elapsed / args.steps) / 1e9, 3),
+                      "host_input_bytes": host_bytes},
+        }
+        print(json.dumps(out))
+    job.close()
+    sb.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

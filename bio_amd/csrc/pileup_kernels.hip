@@ -86,8 +86,17 @@ __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* wi
   win_r1[w] = (int32_t)a;
 }
 
+constexpr int kSub = kW / 8 + 4;     // padded sub-row: 8 residues x kSub
+constexpr int kStride = 8 * kSub;    // dwords per counter plane (multiple of 32)
+constexpr int kUnroll = 4;           // units in flight per lane
+
+// Counter-major LDS histogram, position index permuted by residue mod 8.
+//  * accumulate: the lanes of one record that handle base-in-unit k sit 8 positions apart:
+//    same residue, consecutive (p >> 3) -> consecutive banks, whatever their counter plane
+//    (kStride % 32 == 0), so a record never conflicts with itself at any depth.
+//  * flush: 32 consecutive positions read one plane at banks 4*(p&7) + (p>>3): all distinct.
 __device__ __forceinline__ uint32_t lds_index(uint32_t code, uint32_t p) {
-  return code * kW + (p & 7u) * (kW / 8) + (p >> 3);
+  return code * kStride + (p & 7u) * kSub + (p >> 3);
 }
 
 // Reference position -> read index of record `c` (mate lookup for the overlap rule).
@@ -119,8 +128,12 @@ __device__ __forceinline__ uint32_t clipped_qual(uint32_t q, int32_t b, int32_t 
   return q;
 }
 
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+
+template <bool STITCH>
 __global__ __launch_bounds__(kBlock) void pileup_kernel(KernelParams P) {
-  __shared__ uint32_t cnt[kCodes * kW];
+  __shared__ uint32_t cnt[kCodes * kStride];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -135,10 +148,10 @@ __global__ __launch_bounds__(kBlock) void pileup_kernel(KernelParams P) {
 
   const Window win = P.windows[item];
   const int32_t r0 = P.win_r0[item], r1 = P.win_r1[item];
-  const int32_t g0 = win.g0;
-  const uint32_t wlen = (uint32_t)(win.g1 - win.g0);
+  const int32_t g0 = win.g0, g1 = win.g1;
+  const uint32_t wlen = (uint32_t)(g1 - g0);
 
-  for (int i = tid; i < kCodes * kW / 4; i += kBlock) ((uint4*)cnt)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < kCodes * kStride / 4; i += kBlock) ((uint4*)cnt)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   const int32_t clip = P.clip;
@@ -164,11 +177,18 @@ __global__ __launch_bounds__(kBlock) void pileup_kernel(KernelParams P) {
       // strand filters (pileup.go:717-729)
       if (P.strand_req != 0) keep = keep && strand == P.strand_req;
       else keep = keep && (strand != 0 || P.ignore_strand);
-      keep = keep && ref_id == win.ref_id && pos < win.g1 && (int64_t)pos + span > (int64_t)g0;
-      uint32_t sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
-      if (keep) U = (l_seq + 7) >> 3;
-      // meta: bit0 strand slot, bit1 simple CIGAR, bits 8.. n_cigar
-      meta = sslot | ((aux & AUX_SIMPLE) ? 2u : 0u) | (n_cigar << 8);
+      keep = keep && ref_id == win.ref_id && pos < g1 && (int64_t)pos + span > (int64_t)g0;
+      const uint32_t sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
+      // units (8 read bases) that can touch the window
+      uint32_t u_lo = 0, u_hi = (l_seq + 7) >> 3;
+      if (aux & AUX_SIMPLE) {
+        const int64_t b_lo = (int64_t)g0 - pos, b_hi = (int64_t)g1 - pos;
+        if (b_lo > 0) u_lo = (uint32_t)(b_lo >> 3);
+        if (b_hi < (int64_t)l_seq) u_hi = (uint32_t)((b_hi + 7) >> 3);
+      }
+      if (keep && u_hi > u_lo) U = u_hi - u_lo;
+      // meta: bit0 strand slot, bit1 simple CIGAR, bits 2..15 first unit, bits 16.. n_cigar
+      meta = sslot | ((aux & AUX_SIMPLE) ? 2u : 0u) | (u_lo << 2) | (n_cigar << 16);
     }
     uint32_t Umax = U;
 #pragma unroll
@@ -177,149 +197,180 @@ __global__ __launch_bounds__(kBlock) void pileup_kernel(KernelParams P) {
       Umax = v > Umax ? v : Umax;
     }
     if (Umax == 0) continue;
-    const uint32_t magic = 0xffffffffu / Umax + 1u;
+    const uint32_t magic = (uint32_t)((0x100000000ull + Umax - 1) / Umax);
     const uint32_t total = 64u * Umax;
 
-    // ---- phase 2: lane = unit of 8 bases
-    for (uint32_t t = lane; t < total; t += 64) {
-      uint32_t g = __umulhi(t, magic);
-      if (Umax == 1) g = t;
-      const uint32_t u = t - g * Umax;
-      const uint32_t Ug = (uint32_t)__shfl((int)U, (int)g);
-      const int32_t pos_g = __shfl(pos, (int)g);
-      const uint32_t meta_g = (uint32_t)__shfl((int)meta, (int)g);
-      const uint32_t lseq_g = (uint32_t)__shfl((int)l_seq, (int)g);
-      const uint32_t blob_g = (uint32_t)__shfl((int)blob, (int)g);
-      if (u >= Ug) continue;
-      const uint32_t n_cigar = meta_g >> 8;
-      const uint8_t* bp_ = P.blob + (uint64_t)blob_g * 8;
-      const uint32_t cig_bytes = ((n_cigar + 1) & ~1u) * 4;
-      const uint2 q8v = *(const uint2*)(bp_ + cig_bytes + 8 * u);
-      const uint32_t s4 = *(const uint32_t*)(bp_ + cig_bytes + 8 * Ug + 4 * u);
-      const int32_t b0 = (int32_t)(u * 8);
-
-      // reference position of each of the 8 bases (or INT_MIN: not aligned)
-      int32_t rp[8];
-      if (meta_g & 2u) {
+    // ---- phase 2: lane = unit of 8 bases; kUnroll units in flight per lane
+    for (uint32_t t0 = lane; t0 < total; t0 += 64 * kUnroll) {
+      uint2 q8v[kUnroll];
+      uint32_t s4[kUnroll], meta_g[kUnroll], lseq_g[kUnroll], u_g[kUnroll], gg[kUnroll];
+      int32_t pos_g[kUnroll];
+      const uint8_t* bptr[kUnroll];
+      bool act[kUnroll];
 #pragma unroll
-        for (int k = 0; k < 8; k++) rp[k] = pos_g + b0 + k;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) rp[k] = INT32_MIN;
-        const uint32_t* cg = (const uint32_t*)bp_;
-        int32_t rr = pos_g, qq = 0;
-        for (uint32_t c = 0; c < n_cigar; c++) {
-          const uint32_t op = cg[c] & 15u;
-          const int32_t len = (int32_t)(cg[c] >> 4);
-          if (op == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-              const int32_t b = b0 + k;
-              if (b >= qq && b < qq + len) rp[k] = rr + (b - qq);
-            }
-            rr += len; qq += len;
-          } else if (op == 1 || op == 4) {
-            qq += len;
-          } else if (op == 2 || op == 3) {
-            rr += len;
-          } else if (op != 5) {
-            break;  // host rejected reachable bad ops (pileup.go:355-359)
-          }
-          if (qq >= b0 + 8) break;
+      for (int j = 0; j < kUnroll; j++) {
+        const uint32_t t = t0 + 64u * j;
+        uint32_t g = Umax == 1 ? t : __umulhi(t, magic);
+        g = g > 63u ? 63u : g;
+        const uint32_t uu = t - g * Umax;
+        const uint32_t Ug = (uint32_t)__shfl((int)U, (int)g);
+        pos_g[j] = __shfl(pos, (int)g);
+        meta_g[j] = (uint32_t)__shfl((int)meta, (int)g);
+        lseq_g[j] = (uint32_t)__shfl((int)l_seq, (int)g);
+        const uint32_t blob_g = (uint32_t)__shfl((int)blob, (int)g);
+        act[j] = t < total && uu < Ug;
+        gg[j] = g;
+        const uint32_t u = ((meta_g[j] >> 2) & 0x3fffu) + uu;
+        u_g[j] = u;
+        const uint32_t n_cigar = meta_g[j] >> 16;
+        const uint32_t Utot = (lseq_g[j] + 7) >> 3;
+        bptr[j] = P.blob + (uint64_t)blob_g * 8;
+        q8v[j] = make_uint2(0, 0);
+        s4[j] = 0;
+        if (act[j]) {
+          const uint32_t cig_bytes = ((n_cigar + 1) & ~1u) * 4;
+          q8v[j] = *(const uint2*)(bptr[j] + cig_bytes + 8 * u);
+          s4[j] = *(const uint32_t*)(bptr[j] + cig_bytes + 8 * Utot + 4 * u);
         }
       }
-
-      // stitch: who is my mate
-      int32_t mate_idx = -1;
-      bool second = false;
-      uint32_t sslot = meta_g & 1u;
-      ReadCore mc;
-      if (P.mate != nullptr) {
-        const int32_t m = P.mate[base + (int32_t)g];
-        if (m >= 0) {
-          mate_idx = m >> 1;
-          second = (m & 1) != 0;
-          mc = P.cores[mate_idx];
-          // the pair is counted on the strand of the read that found its mate
-          // (pileup.go:799-802); for the stored read that is the mate's strand
-          if (!second && !P.ignore_strand)
-            sslot = (uint32_t)(strand_of(mc.ref_id, mc.mate_ref_id, mc.flags) - 1) & 1u;
-        }
-      }
-
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int32_t b = b0 + k;
-        const uint32_t p = (uint32_t)(rp[k] - g0);
-        if (b >= (int32_t)lseq_g || rp[k] == INT32_MIN || p >= wlen) continue;
-        const uint32_t byte = s4 >> (8 * (k >> 1));
-        const uint32_t nib = (k & 1) ? (byte & 15u) : ((byte >> 4) & 15u);
-        uint32_t q = ((k < 4 ? q8v.x : q8v.y) >> (8 * (k & 3))) & 0xffu;
-        q = clipped_qual(q, b, (int32_t)lseq_g, clip);
-        const uint32_t c2 = code2_of_nibble(nib);
-        uint32_t code;
-        int32_t mi = -1;
-        if (mate_idx >= 0) mi = read_index_at(mc, P.blob, rp[k]);
-        if (mi >= 0) {
-          // both reads of the pair cover this position (pileup.go:409-430): Depth++ once,
-          // handled by the read that found its mate
-          if (!second) continue;
-          const uint8_t* mb = P.blob + (uint64_t)mc.blob * 8;
-          const uint32_t mcig = ((mc.n_cigar + 1u) & ~1u) * 4;
-          const uint32_t mU = (mc.l_seq + 7) >> 3;
-          uint32_t mq = mb[mcig + mi];
-          const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
-          const uint32_t mnib = (mi & 1) ? (mbyte & 15u) : (mbyte >> 4);
-          mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
-          if (mnib == nib) {
-            if (q >= 96u || mq >= 96u) {
-              // qualPassTable index out of range: a Go runtime panic in the reference
-              atomicMin(&P.err->read, base + (int32_t)g);
-              continue;
-            }
-            const bool pass = mq >= (uint32_t)P.qthr[q] || c2 == 8u;
-            code = pass ? c2 + sslot : 10u;
-          } else {
-            code = 8u + sslot;
-          }
+      for (int j = 0; j < kUnroll; j++) {
+        if (!act[j]) continue;
+        const uint32_t n_cigar = meta_g[j] >> 16;
+        const int32_t b0 = (int32_t)(u_g[j] * 8);
+        const int32_t lseq = (int32_t)lseq_g[j];
+        // reference position of each of the 8 bases, relative to g0 (or a huge value)
+        uint32_t prel[8];
+        if (meta_g[j] & 2u) {
+          const uint32_t p0 = (uint32_t)(pos_g[j] + b0 - g0);
+#pragma unroll
+          for (int k = 0; k < 8; k++) prel[k] = p0 + k;
         } else {
-          // addBase (pileup.go:223-231): N/ambiguous always counted
-          const bool pass = q >= minq || c2 == 8u;
-          code = pass ? c2 + sslot : 10u;
+#pragma unroll
+          for (int k = 0; k < 8; k++) prel[k] = 0xffffffffu;
+          const uint32_t* cg = (const uint32_t*)bptr[j];
+          int32_t rr = pos_g[j], qq = 0;
+          for (uint32_t c = 0; c < n_cigar; c++) {
+            const uint32_t op = cg[c] & 15u;
+            const int32_t len = (int32_t)(cg[c] >> 4);
+            if (op == 0) {
+#pragma unroll
+              for (int k = 0; k < 8; k++) {
+                const int32_t b = b0 + k;
+                if (b >= qq && b < qq + len) prel[k] = (uint32_t)(rr + (b - qq) - g0);
+              }
+              rr += len; qq += len;
+            } else if (op == 1 || op == 4) {
+              qq += len;
+            } else if (op == 2 || op == 3) {
+              rr += len;
+            } else if (op != 5) {
+              break;  // host rejected reachable bad ops (pileup.go:355-359)
+            }
+            if (qq >= b0 + 8) break;
+          }
         }
-        atomicAdd(&cnt[lds_index(code, p)], 1u);
+
+        uint32_t sslot = meta_g[j] & 1u;
+        int32_t mate_idx = -1;
+        bool second = false;
+        ReadCore mc;
+        if constexpr (STITCH) {
+          const int32_t m = P.mate[base + (int32_t)gg[j]];
+          if (m >= 0) {
+            mate_idx = m >> 1;
+            second = (m & 1) != 0;
+            mc = P.cores[mate_idx];
+            // the pair is counted on the strand of the read that found its mate
+            // (pileup.go:799-802); for the stored read that is the mate's strand
+            if (!second && !P.ignore_strand)
+              sslot = (uint32_t)(strand_of(mc.ref_id, mc.mate_ref_id, mc.flags) - 1) & 1u;
+          }
+        }
+        const int32_t nb = lseq - b0;  // valid bases in this unit (may exceed 8)
+
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const uint32_t p = prel[k];
+          if (k >= nb || p >= wlen) continue;
+          const uint32_t nsh = ((k & 1) ? (s4[j] << 2 >> (8 * (k >> 1))) : (s4[j] >> (8 * (k >> 1) + 2))) & 0x3cu;
+          // Seq8ToEnumTable (pileup/common.go:66) x2: nibble 1,2,4,8 -> 0,2,4,6; others 8 (X)
+          const uint32_t c2 = (uint32_t)(0x8888888688848208ull >> nsh) & 15u;
+          uint32_t q = ((k < 4 ? q8v[j].x : q8v[j].y) >> (8 * (k & 3))) & 0xffu;
+          q = clipped_qual(q, b0 + k, lseq, clip);
+          uint32_t code;
+          if constexpr (STITCH) {
+            int32_t mi = -1;
+            const int32_t rp = (int32_t)p + g0;
+            if (mate_idx >= 0) mi = read_index_at(mc, P.blob, rp);
+            if (mi >= 0) {
+              // both reads of the pair cover this position (pileup.go:409-430): Depth++ once,
+              // handled by the read that found its mate
+              if (!second) continue;
+              const uint8_t* mb = P.blob + (uint64_t)mc.blob * 8;
+              const uint32_t mcig = ((mc.n_cigar + 1u) & ~1u) * 4;
+              const uint32_t mU = (mc.l_seq + 7) >> 3;
+              uint32_t mq = mb[mcig + mi];
+              const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
+              const uint32_t mnib = (mi & 1) ? (mbyte & 15u) : (mbyte >> 4);
+              mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
+              if (mnib * 4 == nsh) {
+                if (q >= 96u || mq >= 96u) {
+                  // qualPassTable index out of range: a Go runtime panic in the reference
+                  atomicMin(&P.err->read, base + (int32_t)gg[j]);
+                  continue;
+                }
+                const bool pass = mq >= (uint32_t)P.qthr[q] || c2 == 8u;
+                code = pass ? c2 + sslot : 10u;
+              } else {
+                code = 8u + sslot;
+              }
+            } else {
+              const bool pass = q >= minq || c2 == 8u;
+              code = pass ? c2 + sslot : 10u;
+            }
+          } else {
+            // addBase (pileup.go:223-231): N/ambiguous always counted
+            const bool pass = q >= minq || c2 == 8u;
+            code = pass ? c2 + sslot : 10u;
+          }
+          atomicAdd(&cnt[lds_index(code, p)], 1u);
+        }
       }
     }
   }
   __syncthreads();
 
-  // ---- depth = sum of the 11 counters; kept in slot 10
+  // ---- flush: one lane per position; Depth = sum of the 11 counters (pileup.go:518-570)
   for (uint32_t p = tid; p < wlen; p += kBlock) {
+    uint32_t v[kCodes];
     uint32_t d = 0;
 #pragma unroll
-    for (int c = 0; c < kCodes; c++) d += cnt[lds_index(c, p)];
-    cnt[lds_index(10, p)] = d;
-  }
-  __syncthreads();
-
-  // ---- flush: rows of this window are contiguous in the output
-  uint32_t* out = P.rows + win.row_base * 11;
-  const uint32_t n_out = (uint32_t)win.n_rows * 11u;
-  for (uint32_t d = tid; d < n_out; d += kBlock) {
-    const uint32_t j = d / 11u, f = d - j * 11u;
-    uint32_t p;
+    for (int c = 0; c < kCodes; c++) {
+      v[c] = cnt[lds_index(c, p)];
+      d += v[c];
+    }
+    int64_t R;
     if (win.full) {
-      p = j;
+      R = win.row_base + p;
     } else {
-      const int64_t R = win.row_base + j;
-      uint32_t a = win.iv_lo, b = win.iv_hi;  // last k with iv_row[k] <= R
+      const int32_t gp = g0 + (int32_t)p;
+      uint32_t a = win.iv_lo, b = win.iv_hi;  // last interval with start <= gp
       while (b - a > 1) {
         const uint32_t m = (a + b) >> 1;
-        if (P.iv_row[m] <= R) a = m; else b = m;
+        if (P.iv_start[m] <= gp) a = m; else b = m;
       }
-      p = (uint32_t)(P.iv_start[a] + (int32_t)(R - P.iv_row[a]) - g0);
+      const int32_t is = P.iv_start[a];
+      if (gp < is || gp >= P.iv_end[a]) continue;  // not a BED position
+      R = P.iv_row[a] + (gp - is);
     }
-    out[d] = cnt[lds_index(f == 0 ? 10u : f - 1u, p)];
+    uint32_t* out = P.rows + R * 11;
+    u32x4a o0 = {d, v[0], v[1], v[2]};
+    u32x4a o1 = {v[3], v[4], v[5], v[6]};
+    u32x3a o2 = {v[7], v[8], v[9]};
+    *(u32x4a*)(out) = o0;
+    *(u32x4a*)(out + 4) = o1;
+    *(u32x3a*)(out + 8) = o2;
   }
 }
 
@@ -355,7 +406,8 @@ void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s)
 
 void launch_pileup(const KernelParams& P, hipStream_t s) {
   if (P.n_windows == 0) return;
-  hipLaunchKernelGGL(pileup_kernel, dim3(P.n_windows), dim3(kBlock), 0, s, P);
+  if (P.stitch) hipLaunchKernelGGL(pileup_kernel<true>, dim3(P.n_windows), dim3(kBlock), 0, s, P);
+  else hipLaunchKernelGGL(pileup_kernel<false>, dim3(P.n_windows), dim3(kBlock), 0, s, P);
 }
 
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s) {

@@ -29,8 +29,8 @@
 namespace bp {
 
 constexpr int kW = 1024;       // window positions
-constexpr int kBlock = 256;    // threads per workgroup
-constexpr int kCodes = 11;     // 10 count slots + depth-only
+constexpr int kBlock = 512;    // threads per workgroup
+constexpr int kPlanes = 12;    // 10 count planes + 2 depth-only planes
 
 __device__ __forceinline__ int strand_of(int32_t ref, int32_t mate_ref, uint32_t flags) {
   // pileup.GetStrand (pileup/common.go:94-114)
@@ -88,16 +88,29 @@ __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* wi
 
 constexpr int kSub = kW / 8 + 4;     // padded sub-row: 8 residues x kSub
 constexpr int kStride = 8 * kSub;    // dwords per counter plane (multiple of 32)
-constexpr int kUnroll = 4;           // units in flight per lane
+constexpr int kSegCap = 512;         // M-segments per round
+constexpr int kUnitCap = 8192;       // units (8 window positions of one segment) per round
+constexpr int kUnroll = 2;           // units in flight per lane
 
-// Counter-major LDS histogram, position index permuted by residue mod 8.
-//  * accumulate: the lanes of one record that handle base-in-unit k sit 8 positions apart:
-//    same residue, consecutive (p >> 3) -> consecutive banks, whatever their counter plane
-//    (kStride % 32 == 0), so a record never conflicts with itself at any depth.
-//  * flush: 32 consecutive positions read one plane at banks 4*(p&7) + (p>>3): all distinct.
-__device__ __forceinline__ uint32_t lds_index(uint32_t code, uint32_t p) {
-  return code * kStride + (p & 7u) * kSub + (p >> 3);
-}
+// LDS histogram: 12 counter planes (A+ A- C+ C- G+ G- T+ T- X+ X- lowq+ lowq-), each plane
+// laid out by residue: position p = 8j + k lives at k*kSub + j.
+//  * accumulate: a lane handles the 8 positions of unit j of one M-segment, so its 8
+//    ds_add_u32 differ only in the instruction's immediate offset (k*kSub*4); consecutive
+//    lanes hold consecutive j of the same segment -> consecutive banks, and kStride % 32 == 0
+//    keeps that true across planes: a record never conflicts with itself at any depth.
+//  * flush: 32 consecutive positions of one plane sit at banks 4k + j: all distinct.
+struct __align__(16) BlockShared {
+  uint32_t cnt[kPlanes * kStride];
+  // segment list of the current round (structure of arrays)
+  int32_t s_ref[kSegCap];       // segment start relative to the window start (may be < 0)
+  uint32_t s_lenq0[kSegCap];    // length | read offset << 16
+  uint32_t s_blob[kSegCap];     // record payload offset (8-byte units)
+  uint32_t s_lseqnc[kSegCap];   // l_seq | n_cigar << 16
+  uint32_t s_misc[kSegCap];     // first unit slot | strand slot << 15 | first window unit << 16
+  int32_t s_rec[kSegCap];       // record index (stitch)
+  uint16_t owner[kUnitCap];     // unit slot -> segment
+  uint32_t n_seg, n_units;
+};
 
 // Reference position -> read index of record `c` (mate lookup for the overlap rule).
 // Returns -1 when no M op of the record covers ref position `rp`.
@@ -124,140 +137,114 @@ __device__ int32_t read_index_at(const ReadCore& c, const uint8_t* blob, int32_t
 
 __device__ __forceinline__ uint32_t clipped_qual(uint32_t q, int32_t b, int32_t l_seq, int32_t clip) {
   // clipQuals (pileup_support.go:51-69)
-  if (clip > 0 && (2 * clip >= l_seq || b < clip || b >= l_seq - clip)) return 2u;
+  if (2 * clip >= l_seq || b < clip || b >= l_seq - clip) return 2u;
   return q;
 }
 
 typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
 
-template <bool STITCH>
-__global__ __launch_bounds__(kBlock) void pileup_kernel(KernelParams P) {
-  __shared__ uint32_t cnt[kCodes * kStride];
+// Admit one M-segment into the round's list.  Returns false when the round is full: the
+// caller keeps its cursor and retries next round.
+__device__ __forceinline__ bool try_emit(BlockShared& S, int32_t sref, int32_t len, int32_t q0,
+                                         uint32_t wlen, uint32_t blob, uint32_t lseqnc,
+                                         uint32_t sslot, int32_t rec) {
+  const int32_t s1 = sref > 0 ? sref : 0;
+  const int32_t e1 = (int64_t)sref + len < (int64_t)wlen ? sref + len : (int32_t)wlen;
+  if (e1 <= s1) return true;
+  const uint32_t jlo = (uint32_t)s1 >> 3, jhi = (uint32_t)(e1 - 1) >> 3;
+  const uint32_t U = jhi - jlo + 1;
+  const uint32_t idx = atomicAdd(&S.n_seg, 1u);
+  const uint32_t us = atomicAdd(&S.n_units, U);
+  const bool ok = idx < (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
+  if (ok) {
+    S.s_ref[idx] = sref;
+    S.s_lenq0[idx] = (uint32_t)len | ((uint32_t)q0 << 16);
+    S.s_blob[idx] = blob;
+    S.s_lseqnc[idx] = lseqnc;
+    S.s_misc[idx] = us | (sslot << 15) | (jlo << 16);
+    S.s_rec[idx] = rec;
+    for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
+  } else {
+    for (uint32_t i = us; i < us + U && i < (uint32_t)kUnitCap; i++) S.owner[i] = 0xffffu;
+  }
+  return ok;
+}
+
+template <bool STITCH, bool CLIP>
+__global__ __launch_bounds__(kBlock, 4) void pileup_kernel(KernelParams P) {
+  __shared__ BlockShared S;
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  constexpr int kWaves = kBlock / 64;
 
   // XCD-aware item order: workgroups b and b+8 share an XCD (and its L2); give each XCD a
   // contiguous run of windows so records straddling two windows are re-read from L2.
   const uint32_t nwg = gridDim.x;
-  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
   const uint32_t q8 = nwg >> 3, r8 = nwg & 7u;
-  const uint32_t item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const uint32_t item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
 
   const Window win = P.windows[item];
   const int32_t r0 = P.win_r0[item], r1 = P.win_r1[item];
   const int32_t g0 = win.g0, g1 = win.g1;
   const uint32_t wlen = (uint32_t)(g1 - g0);
 
-  for (int i = tid; i < kCodes * kStride / 4; i += kBlock) ((uint4*)cnt)[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
+  for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
 
   const int32_t clip = P.clip;
   const uint32_t minq = (uint32_t)P.min_base_qual;
 
-  for (int32_t base = r0 + wave * 64; base < r1; base += kWaves * 64) {
-    // ---- phase 1: lane = record; read-level filters
-    const int32_t r = base + lane;
-    uint32_t U = 0, meta = 0, l_seq = 0, blob = 0;
-    int32_t pos = 0;
-    if (r < r1) {
-      const uint4* cp = (const uint4*)(P.cores + r);
-      uint4 c0 = cp[0], c1 = cp[1];
-      pos = (int32_t)c0.x;
-      const int32_t ref_id = (int32_t)c0.y, mate_ref = (int32_t)c0.w;
-      const uint32_t flags = c1.x & 0xffffu, mapq = (c1.x >> 16) & 0xffu, aux = c1.x >> 24;
-      const uint32_t n_cigar = c1.y & 0xffffu, span = c1.y >> 16;
-      l_seq = c1.z;
-      blob = c1.w;
-      const int strand = strand_of(ref_id, mate_ref, flags);
-      // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
-      bool keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
-      // strand filters (pileup.go:717-729)
-      if (P.strand_req != 0) keep = keep && strand == P.strand_req;
-      else keep = keep && (strand != 0 || P.ignore_strand);
-      keep = keep && ref_id == win.ref_id && pos < g1 && (int64_t)pos + span > (int64_t)g0;
-      const uint32_t sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
-      // units (8 read bases) that can touch the window
-      uint32_t u_lo = 0, u_hi = (l_seq + 7) >> 3;
-      if (aux & AUX_SIMPLE) {
-        const int64_t b_lo = (int64_t)g0 - pos, b_hi = (int64_t)g1 - pos;
-        if (b_lo > 0) u_lo = (uint32_t)(b_lo >> 3);
-        if (b_hi < (int64_t)l_seq) u_hi = (uint32_t)((b_hi + 7) >> 3);
-      }
-      if (keep && u_hi > u_lo) U = u_hi - u_lo;
-      // meta: bit0 strand slot, bit1 simple CIGAR, bits 2..15 first unit, bits 16.. n_cigar
-      meta = sslot | ((aux & AUX_SIMPLE) ? 2u : 0u) | (u_lo << 2) | (n_cigar << 16);
-    }
-    uint32_t Umax = U;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      uint32_t v = (uint32_t)__shfl_xor((int)Umax, o);
-      Umax = v > Umax ? v : Umax;
-    }
-    if (Umax == 0) continue;
-    const uint32_t magic = (uint32_t)((0x100000000ull + Umax - 1) / Umax);
-    const uint32_t total = 64u * Umax;
+  // per-thread record cursor
+  int32_t rec = r0 + tid;
+  bool have = false, keep = false;
+  uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, sslot = 0, aux = 0, span = 0;
+  int32_t rr = 0, qq = 0;
 
-    // ---- phase 2: lane = unit of 8 bases; kUnroll units in flight per lane
-    for (uint32_t t0 = lane; t0 < total; t0 += 64 * kUnroll) {
-      uint2 q8v[kUnroll];
-      uint32_t s4[kUnroll], meta_g[kUnroll], lseq_g[kUnroll], u_g[kUnroll], gg[kUnroll];
-      int32_t pos_g[kUnroll];
-      const uint8_t* bptr[kUnroll];
-      bool act[kUnroll];
-#pragma unroll
-      for (int j = 0; j < kUnroll; j++) {
-        const uint32_t t = t0 + 64u * j;
-        uint32_t g = Umax == 1 ? t : __umulhi(t, magic);
-        g = g > 63u ? 63u : g;
-        const uint32_t uu = t - g * Umax;
-        const uint32_t Ug = (uint32_t)__shfl((int)U, (int)g);
-        pos_g[j] = __shfl(pos, (int)g);
-        meta_g[j] = (uint32_t)__shfl((int)meta, (int)g);
-        lseq_g[j] = (uint32_t)__shfl((int)l_seq, (int)g);
-        const uint32_t blob_g = (uint32_t)__shfl((int)blob, (int)g);
-        act[j] = t < total && uu < Ug;
-        gg[j] = g;
-        const uint32_t u = ((meta_g[j] >> 2) & 0x3fffu) + uu;
-        u_g[j] = u;
-        const uint32_t n_cigar = meta_g[j] >> 16;
-        const uint32_t Utot = (lseq_g[j] + 7) >> 3;
-        bptr[j] = P.blob + (uint64_t)blob_g * 8;
-        q8v[j] = make_uint2(0, 0);
-        s4[j] = 0;
-        if (act[j]) {
-          const uint32_t cig_bytes = ((n_cigar + 1) & ~1u) * 4;
-          q8v[j] = *(const uint2*)(bptr[j] + cig_bytes + 8 * u);
-          s4[j] = *(const uint32_t*)(bptr[j] + cig_bytes + 8 * Utot + 4 * u);
-        }
+  for (;;) {
+    if (tid == 0) {
+      S.n_seg = 0;
+      S.n_units = 0;
+    }
+    __syncthreads();
+    // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
+    if (rec < r1) {
+      if (!have) {
+        const uint4* cp = (const uint4*)(P.cores + rec);
+        const uint4 c0 = cp[0], c1 = cp[1];
+        const int32_t pos = (int32_t)c0.x;
+        const int32_t ref_id = (int32_t)c0.y, mate_ref = (int32_t)c0.w;
+        const uint32_t flags = c1.x & 0xffffu, mapq = (c1.x >> 16) & 0xffu;
+        aux = c1.x >> 24;
+        n_cigar = c1.y & 0xffffu;
+        span = c1.y >> 16;
+        blob = c1.w;
+        lseqnc = (c1.z & 0xffffu) | (n_cigar << 16);
+        const int strand = strand_of(ref_id, mate_ref, flags);
+        // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
+        keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
+        // strand filters (pileup.go:717-729)
+        if (P.strand_req != 0) keep = keep && strand == P.strand_req;
+        else keep = keep && (strand != 0 || P.ignore_strand);
+        keep = keep && ref_id == win.ref_id && pos < g1 && (int64_t)pos + span > (int64_t)g0;
+        sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
+        c_cur = 0;
+        rr = pos - g0;
+        qq = 0;
+        have = true;
       }
-#pragma unroll
-      for (int j = 0; j < kUnroll; j++) {
-        if (!act[j]) continue;
-        const uint32_t n_cigar = meta_g[j] >> 16;
-        const int32_t b0 = (int32_t)(u_g[j] * 8);
-        const int32_t lseq = (int32_t)lseq_g[j];
-        // reference position of each of the 8 bases, relative to g0 (or a huge value)
-        uint32_t prel[8];
-        if (meta_g[j] & 2u) {
-          const uint32_t p0 = (uint32_t)(pos_g[j] + b0 - g0);
-#pragma unroll
-          for (int k = 0; k < 8; k++) prel[k] = p0 + k;
+      bool done = true;
+      if (keep) {
+        if (aux & AUX_SIMPLE) {
+          done = try_emit(S, rr, (int32_t)span, 0, wlen, blob, lseqnc, sslot, rec);
         } else {
-#pragma unroll
-          for (int k = 0; k < 8; k++) prel[k] = 0xffffffffu;
-          const uint32_t* cg = (const uint32_t*)bptr[j];
-          int32_t rr = pos_g[j], qq = 0;
-          for (uint32_t c = 0; c < n_cigar; c++) {
-            const uint32_t op = cg[c] & 15u;
-            const int32_t len = (int32_t)(cg[c] >> 4);
+          const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
+          while (c_cur < n_cigar) {
+            const uint32_t op = cg[c_cur] & 15u;
+            const int32_t len = (int32_t)(cg[c_cur] >> 4);
             if (op == 0) {
-#pragma unroll
-              for (int k = 0; k < 8; k++) {
-                const int32_t b = b0 + k;
-                if (b >= qq && b < qq + len) prel[k] = (uint32_t)(rr + (b - qq) - g0);
+              if (!try_emit(S, rr, len, qq, wlen, blob, lseqnc, sslot, rec)) {
+                done = false;
+                break;
               }
               rr += len; qq += len;
             } else if (op == 1 || op == 4) {
@@ -267,16 +254,92 @@ __global__ __launch_bounds__(kBlock) void pileup_kernel(KernelParams P) {
             } else if (op != 5) {
               break;  // host rejected reachable bad ops (pileup.go:355-359)
             }
-            if (qq >= b0 + 8) break;
+            c_cur++;
+            if (rr >= (int32_t)wlen) break;
           }
         }
+      }
+      if (done) {
+        rec += kBlock;
+        have = false;
+      }
+    }
+    const int pending = rec < r1;
+    __syncthreads();
 
-        uint32_t sslot = meta_g[j] & 1u;
+    // ---- phase 2: thread = unit (8 window positions of one segment)
+    const uint32_t T = S.n_units < (uint32_t)kUnitCap ? S.n_units : (uint32_t)kUnitCap;
+    for (uint32_t t0 = tid; t0 < T; t0 += kBlock * kUnroll) {
+      u32x3a qd[kUnroll];
+      u32x2a sd[kUnroll];
+      int32_t sref[kUnroll], b0[kUnroll];
+      uint32_t lenq0[kUnroll], lseqnc_u[kUnroll], jj[kUnroll], sl[kUnroll], seg[kUnroll];
+      bool act[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        const uint32_t t = t0 + (uint32_t)kBlock * u;
+        act[u] = false;
+        seg[u] = 0;
+        if (t < T) {
+          const uint32_t s = S.owner[t];
+          if (s != 0xffffu) {
+            act[u] = true;
+            seg[u] = s;
+            sref[u] = S.s_ref[s];
+            lenq0[u] = S.s_lenq0[s];
+            lseqnc_u[u] = S.s_lseqnc[s];
+            const uint32_t misc = S.s_misc[s];
+            const uint32_t bl = S.s_blob[s];
+            sl[u] = (misc >> 15) & 1u;
+            jj[u] = (misc >> 16) + (t - (misc & 0x7fffu));
+            const int32_t Pw = (int32_t)(jj[u] * 8);
+            b0[u] = (int32_t)(lenq0[u] >> 16) + (Pw - sref[u]);
+            const uint32_t nc = lseqnc_u[u] >> 16, lseq = lseqnc_u[u] & 0xffffu;
+            const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
+            const int32_t qoff = cigb + b0[u];
+            const int32_t soff = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b0[u] >> 1);
+            const uint8_t* bp_ = P.blob + (uint64_t)bl * 8;
+            qd[u] = *(const u32x3a*)(bp_ + (qoff & ~3));
+            sd[u] = *(const u32x2a*)(bp_ + (soff & ~3));
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        if (!act[u]) continue;
+        const int32_t Pw = (int32_t)(jj[u] * 8);
+        const int32_t len = (int32_t)(lenq0[u] & 0xffffu);
+        const uint32_t nc = lseqnc_u[u] >> 16, lseq = lseqnc_u[u] & 0xffffu;
+        const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
+        const int32_t qoff = cigb + b0[u];
+        const int32_t soff = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b0[u] >> 1);
+        // which of the 8 positions belong to the segment and the window
+        int32_t klo = sref[u] - Pw;
+        klo = klo > 0 ? klo : 0;
+        int32_t e = sref[u] + len;
+        e = e < (int32_t)wlen ? e : (int32_t)wlen;
+        int32_t khi = e - Pw;
+        khi = khi < 8 ? khi : 8;
+        uint32_t mask = ((1u << khi) - 1u) & ~((1u << klo) - 1u);
+        // 8 quals and 8 nibbles, realigned to the unit
+        const uint32_t qsh = (uint32_t)qoff & 3u;
+        const uint32_t qlo = __builtin_amdgcn_alignbyte(qd[u].y, qd[u].x, qsh);
+        const uint32_t qhi = __builtin_amdgcn_alignbyte(qd[u].z, qd[u].y, qsh);
+        // BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i
+        // (this is the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
+        const uint32_t x0 = ((sd[u].x & 0x0f0f0f0fu) << 4) | ((sd[u].x >> 4) & 0x0f0f0f0fu);
+        const uint32_t x1 = ((sd[u].y & 0x0f0f0f0fu) << 4) | ((sd[u].y >> 4) & 0x0f0f0f0fu);
+        const uint32_t noff = 2u * ((uint32_t)soff & 3u) + ((uint32_t)b0[u] & 1u);
+        const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, 4u * noff);
+        uint32_t sslot_u = sl[u];
+
         int32_t mate_idx = -1;
         bool second = false;
         ReadCore mc;
+        int32_t myrec = 0;
         if constexpr (STITCH) {
-          const int32_t m = P.mate[base + (int32_t)gg[j]];
+          myrec = S.s_rec[seg[u]];
+          const int32_t m = P.mate[myrec];
           if (m >= 0) {
             mate_idx = m >> 1;
             second = (m & 1) != 0;
@@ -284,70 +347,73 @@ __global__ __launch_bounds__(kBlock) void pileup_kernel(KernelParams P) {
             // the pair is counted on the strand of the read that found its mate
             // (pileup.go:799-802); for the stored read that is the mate's strand
             if (!second && !P.ignore_strand)
-              sslot = (uint32_t)(strand_of(mc.ref_id, mc.mate_ref_id, mc.flags) - 1) & 1u;
+              sslot_u = (uint32_t)(strand_of(mc.ref_id, mc.mate_ref_id, mc.flags) - 1) & 1u;
           }
         }
-        const int32_t nb = lseq - b0;  // valid bases in this unit (may exceed 8)
+        uint32_t* const cb = S.cnt + sslot_u * kStride + jj[u];
 
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          const uint32_t p = prel[k];
-          if (k >= nb || p >= wlen) continue;
-          const uint32_t nsh = ((k & 1) ? (s4[j] << 2 >> (8 * (k >> 1))) : (s4[j] >> (8 * (k >> 1) + 2))) & 0x3cu;
-          // Seq8ToEnumTable (pileup/common.go:66) x2: nibble 1,2,4,8 -> 0,2,4,6; others 8 (X)
+          const uint32_t nsh = (k == 0 ? (sw << 2) : (sw >> (4 * k - 2))) & 0x3cu;
+          // Seq8ToEnumTable (pileup/common.go:66) x2: nibble 1,2,4,8 -> 0,2,4,6; others 8 (X);
+          // and the plane a base failing the quality rule goes to: X stays X (always counted,
+          // pileup.go:227), others go to the depth-only plane 10.
           const uint32_t c2 = (uint32_t)(0x8888888688848208ull >> nsh) & 15u;
-          uint32_t q = ((k < 4 ? q8v[j].x : q8v[j].y) >> (8 * (k & 3))) & 0xffu;
-          q = clipped_qual(q, b0 + k, lseq, clip);
+          const uint32_t cf = (uint32_t)(0x8888888a888a8aa8ull >> nsh) & 15u;
+          uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
+          if constexpr (CLIP) q = clipped_qual(q, b0[u] + k, (int32_t)lseq, clip);
+          uint32_t val = (mask >> k) & 1u;
           uint32_t code;
           if constexpr (STITCH) {
-            int32_t mi = -1;
-            const int32_t rp = (int32_t)p + g0;
-            if (mate_idx >= 0) mi = read_index_at(mc, P.blob, rp);
-            if (mi >= 0) {
-              // both reads of the pair cover this position (pileup.go:409-430): Depth++ once,
-              // handled by the read that found its mate
-              if (!second) continue;
-              const uint8_t* mb = P.blob + (uint64_t)mc.blob * 8;
-              const uint32_t mcig = ((mc.n_cigar + 1u) & ~1u) * 4;
-              const uint32_t mU = (mc.l_seq + 7) >> 3;
-              uint32_t mq = mb[mcig + mi];
-              const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
-              const uint32_t mnib = (mi & 1) ? (mbyte & 15u) : (mbyte >> 4);
-              mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
-              if (mnib * 4 == nsh) {
-                if (q >= 96u || mq >= 96u) {
-                  // qualPassTable index out of range: a Go runtime panic in the reference
-                  atomicMin(&P.err->read, base + (int32_t)gg[j]);
-                  continue;
+            code = q >= minq ? c2 : cf;
+            if (mate_idx >= 0 && val) {
+              const int32_t rp = Pw + k + g0;
+              const int32_t mi = read_index_at(mc, P.blob, rp);
+              if (mi >= 0) {
+                // both reads of the pair cover this position (pileup.go:409-430): Depth++ once,
+                // handled by the read that found its mate
+                if (!second) {
+                  val = 0;
+                } else {
+                  const uint8_t* mb = P.blob + (uint64_t)mc.blob * 8;
+                  const uint32_t mcig = ((mc.n_cigar + 1u) & ~1u) * 4;
+                  const uint32_t mU = (mc.l_seq + 7) >> 3;
+                  uint32_t mq = mb[mcig + mi];
+                  const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
+                  const uint32_t mnib = (mi & 1) ? (mbyte & 15u) : (mbyte >> 4);
+                  if constexpr (CLIP) mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
+                  if (mnib * 4 == nsh) {
+                    if (q >= 96u || mq >= 96u) {
+                      // qualPassTable index out of range: a Go runtime panic in the reference
+                      atomicMin(&P.err->read, myrec);
+                      val = 0;
+                    } else {
+                      code = mq >= (uint32_t)P.qthr[q] ? c2 : cf;
+                    }
+                  } else {
+                    code = 8u;
+                  }
                 }
-                const bool pass = mq >= (uint32_t)P.qthr[q] || c2 == 8u;
-                code = pass ? c2 + sslot : 10u;
-              } else {
-                code = 8u + sslot;
               }
-            } else {
-              const bool pass = q >= minq || c2 == 8u;
-              code = pass ? c2 + sslot : 10u;
             }
           } else {
-            // addBase (pileup.go:223-231): N/ambiguous always counted
-            const bool pass = q >= minq || c2 == 8u;
-            code = pass ? c2 + sslot : 10u;
+            // addBase (pileup.go:223-231)
+            code = q >= minq ? c2 : cf;
           }
-          atomicAdd(&cnt[lds_index(code, p)], 1u);
+          atomicAdd(cb + code * kStride + k * kSub, val);
         }
       }
     }
+    if (!__syncthreads_or(pending)) break;
   }
-  __syncthreads();
 
-  // ---- flush: one lane per position; Depth = sum of the 11 counters (pileup.go:518-570)
+  // ---- flush: one lane per position; Depth = sum of the 12 planes (pileup.go:518-570)
   for (uint32_t p = tid; p < wlen; p += kBlock) {
-    uint32_t v[kCodes];
+    uint32_t v[kPlanes];
     uint32_t d = 0;
 #pragma unroll
-    for (int c = 0; c < kCodes; c++) {
-      v[c] = cnt[lds_index(c, p)];
+    for (int c = 0; c < kPlanes; c++) {
+      v[c] = S.cnt[c * kStride + (p & 7u) * kSub + (p >> 3)];
       d += v[c];
     }
     int64_t R;
@@ -406,8 +472,15 @@ void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s)
 
 void launch_pileup(const KernelParams& P, hipStream_t s) {
   if (P.n_windows == 0) return;
-  if (P.stitch) hipLaunchKernelGGL(pileup_kernel<true>, dim3(P.n_windows), dim3(kBlock), 0, s, P);
-  else hipLaunchKernelGGL(pileup_kernel<false>, dim3(P.n_windows), dim3(kBlock), 0, s, P);
+  const dim3 g(P.n_windows), b(kBlock);
+  const bool clip = P.clip > 0;
+  if (P.stitch) {
+    if (clip) hipLaunchKernelGGL((pileup_kernel<true, true>), g, b, 0, s, P);
+    else hipLaunchKernelGGL((pileup_kernel<true, false>), g, b, 0, s, P);
+  } else {
+    if (clip) hipLaunchKernelGGL((pileup_kernel<false, true>), g, b, 0, s, P);
+    else hipLaunchKernelGGL((pileup_kernel<false, false>), g, b, 0, s, P);
+  }
 }
 
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s) {

@@ -27,3 +27,8 @@ clean:
 	rm -f bio_amd/*.so
 	$(MAKE) -C oracle clean
 .PHONY: all lib synth oracle clean
+
+# diagnostic build with in-kernel phase stamps (never shipped; see tools/phase_stamps.py)
+stamps: bio_amd/libbiopileup_stamps.so
+bio_amd/libbiopileup_stamps.so: $(LIB_SRCS) $(LIB_HDRS)
+	$(HIPCC) $(HIPFLAGS) -DBP_STAMPS -shared -o $@ $(LIB_SRCS) -lz -lpthread

@@ -7,7 +7,8 @@ BP_OK, BP_EINVAL, BP_EDEVICE, BP_ENOMEM, BP_EDATA, BP_EUNSORTED = 0, -1, -2, -3,
 STRAND_NONE, STRAND_FWD, STRAND_REV = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbiopileup.so")
+# BIO_AMD_LIB selects another build of the same library (diagnostic / tuning variants)
+LIB_PATH = os.environ.get("BIO_AMD_LIB") or os.path.join(_HERE, "libbiopileup.so")
 SYNTH_LIB_PATH = os.path.join(_HERE, "libbpsynth.so")
 
 

@@ -89,6 +89,9 @@ struct bp_handle {
   int64_t algo_in_bytes = 0;
   uint64_t last_key = 0;
   int32_t max_span = 1;
+  std::vector<int64_t> ref_first;  // [n_ref+1] first record index of each reference
+  std::vector<int64_t> ref_first_closed;  // copy uploaded by bp_compute (kept alive for the async copy)
+  int32_t cur_ref = 0;             // references < cur_ref are complete
 
   // stitch: host mate table
   std::vector<MateRef> mate;                          // per record
@@ -100,7 +103,7 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first;
   Staging stage[2];
   int cur_stage = 0;
   bp_timing timing{};
@@ -351,6 +354,12 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1,
       return fail(h, BP_EUNSORTED, "bp_submit: record %lld (ref %d pos %d) is out of coordinate order",
                   (long long)(h->n_reads + (i - i0)), ref, pos);
     h->last_key = key;
+    {
+      // records of reference r occupy [ref_first[r], ref_first[r+1]); unmapped (-1) sort last
+      const int32_t nref = (int32_t)h->ref_len.size();
+      const int32_t rclamp = (ref < 0 || ref >= nref) ? nref : ref;
+      while (h->cur_ref < rclamp) h->ref_first[(size_t)++h->cur_ref] = h->n_reads + (i - i0);
+    }
     const uint32_t n_cigar = b->n_cigar[i];
     if (n_cigar > 0xffffu)
       return fail(h, BP_EINVAL, "bp_submit: record with %u CIGAR ops (limit 65535)", n_cigar);
@@ -496,6 +505,7 @@ int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const 
     for (int i = 0; i < n_ref; i++)
       if (ref_name[i]) h->ref_name[(size_t)i] = ref_name[i];
   h->bed.resize((size_t)n_ref);
+  h->ref_first.assign((size_t)n_ref + 1, 0);
   if (int rc = build_qthr(h)) { delete h; return rc; }
   auto bail = [&](const char* what, hipError_t e) {
     int rc = fail(nullptr, BP_EDEVICE, "%s: %s", what, hipGetErrorString(e));
@@ -584,16 +594,16 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
         ReadCore& rc = st->cores[k];
         const uint32_t n_cigar = b->n_cigar[i], l = b->l_seq[i];
         rc.pos = b->pos[i];
-        rc.ref_id = b->ref_id[i];
-        rc.mate_pos = b->mate_pos[i];
-        rc.mate_ref_id = b->mate_ref_id[i];
         rc.flags = b->flags[i];
         rc.mapq = b->mapq[i];
-        rc.aux = simple[k] ? AUX_SIMPLE : 0;
+        rc.aux = (uint8_t)((simple[k] ? AUX_SIMPLE : 0) |
+                           (b->ref_id[i] == b->mate_ref_id[i] ? AUX_MATE_SAME : 0));
         rc.n_cigar = (uint16_t)n_cigar;
         rc.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
-        rc.l_seq = l;
+        rc.l_seq = (uint16_t)std::min<uint32_t>(l, 0xffffu);
+        rc.pad = 0;
         rc.blob = blob_base + (uint32_t)(boff[k] / 8);
+        for (uint32_t c = 0; c < 3; c++) rc.cig[c] = c < n_cigar ? b->cigar[b->cigar_off[i] + c] : 0u;
         uint8_t* d = st->blob + boff[k];
         const uint32_t ncp = (n_cigar + 1) & ~1u;
         memcpy(d, b->cigar + b->cigar_off[i], (size_t)n_cigar * 4);
@@ -641,6 +651,17 @@ int bp_compute(bp_handle* h) {
   if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
   if (int rc = ensure(h, h->d_cores, 256, 0)) return rc;
   if (int rc = ensure(h, h->d_blob, 256, 0)) return rc;
+  {
+    // close the per-reference record ranges: references after the last one seen are empty
+    std::vector<int64_t>& rf = h->ref_first_closed;
+    rf = h->ref_first;
+    const size_t nref = h->ref_len.size();
+    // rf[r] = first record with reference >= r, valid for r <= cur_ref (unmapped records
+    // count as reference n_ref); references not reached yet are empty and start at the end
+    for (size_t r = (size_t)h->cur_ref + 1; r <= nref; r++) rf[r] = h->n_reads;
+    if (int rc = ensure(h, h->d_ref_first, (nref + 1) * 8 + 256, 0)) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_ref_first.p, rf.data(), (nref + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  }
   DeviceError init{0x7fffffff, ERR_NONE};
   HIP_TRY(h, hipMemcpyAsync(h->d_err.p, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
   KernelParams P{};
@@ -650,12 +671,19 @@ int bp_compute(bp_handle* h) {
   P.windows = (const Window*)h->d_windows.p;
   P.win_r0 = (const int32_t*)h->d_r0.p;
   P.win_r1 = (const int32_t*)h->d_r1.p;
+  P.ref_first = (const int64_t*)h->d_ref_first.p;
   P.iv_start = (const int32_t*)h->d_iv_start.p;
   P.iv_end = (const int32_t*)h->d_iv_end.p;
   P.iv_row = (const int64_t*)h->d_iv_row.p;
   P.rows = (uint32_t*)h->d_rows.p;
   P.err = (DeviceError*)h->d_err.p;
   P.qthr = (const uint8_t*)h->d_qthr.p;
+  P.dbg = nullptr;
+#ifdef BP_STAMPS
+  if (int rc = ensure(h, h->d_dbg, h->windows.size() * 8 * 8 * 8 + 256, 0)) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_dbg.p, 0, h->windows.size() * 8 * 8 * 8, h->stream));
+  P.dbg = (unsigned long long*)h->d_dbg.p;
+#endif
   P.n_reads = h->n_reads;
   P.n_windows = (int32_t)h->windows.size();
   P.max_span = h->max_span;
@@ -762,6 +790,13 @@ int64_t bp_algorithmic_bytes(const bp_handle* h) {
   return h->algo_in_bytes + 44 * bp_num_rows(h);
 }
 
+#ifdef BP_STAMPS
+// diagnostic build only: copy the phase stamps of the last bp_compute (n_windows*8*8 u64)
+int bp_debug_stamps(bp_handle* h, unsigned long long* out, int64_t n) {
+  return hipMemcpy(out, h->d_dbg.p, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 const char* bp_last_error(const bp_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
 void bp_destroy(bp_handle* h) {
@@ -769,7 +804,7 @@ void bp_destroy(bp_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
-                    &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr})
+                    &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {
     if (s.cores) (void)hipHostFree(s.cores);

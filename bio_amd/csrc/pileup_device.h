@@ -4,25 +4,30 @@
 
 namespace bp {
 
-// One alignment record's fixed part, 32 bytes (same size as the BAM fixed block decoded at
-// encoding/bam/unmarshal.go:126-224).  `span` is the reference span sam.Cigar.Lengths()
-// returns (pileup.go:769), clamped to 0xffff; `aux` bit 0 = CIGAR is a single M op.
+// One alignment record's fixed part, 32 bytes (the size of the BAM fixed block decoded at
+// encoding/bam/unmarshal.go:126-224).  Fields the kernels never read (mate position, bin,
+// tlen, the reference id -- records of one reference are a contiguous index range) make
+// room for the first three CIGAR ops, so that a record with <= 3 ops (virtually all) needs
+// no dependent load before its payload.  `span` is the reference span sam.Cigar.Lengths()
+// returns (pileup.go:769), clamped to 0xffff.
 struct ReadCore {
   int32_t pos;
-  int32_t ref_id;
-  int32_t mate_pos;
-  int32_t mate_ref_id;
   uint16_t flags;
   uint8_t mapq;
-  uint8_t aux;
+  uint8_t aux;       // AUX_* bits
   uint16_t n_cigar;
   uint16_t span;
-  uint32_t l_seq;
-  uint32_t blob;  // offset of the record's payload in 8-byte units
+  uint16_t l_seq;    // clamped to 0xffff (longer records never pass max-read-len)
+  uint16_t pad;
+  uint32_t blob;     // offset of the record's payload in 8-byte units
+  uint32_t cig[3];   // first three CIGAR ops (the payload holds all of them)
 };
 static_assert(sizeof(ReadCore) == 32, "ReadCore must be 32 bytes");
 
-enum : uint8_t { AUX_SIMPLE = 1 };
+enum : uint8_t {
+  AUX_SIMPLE = 1,     // CIGAR is a single M op
+  AUX_MATE_SAME = 2   // Ref == MateRef (first test of pileup.GetStrand, common.go:95)
+};
 
 // Payload ("blob") of a record, 8-byte aligned:
 //   uint32 cigar[n_cigar rounded up to even]
@@ -66,12 +71,14 @@ struct KernelParams {
   const Window* windows;
   const int32_t* win_r0;      // per window: first record that may overlap it
   const int32_t* win_r1;      // per window: one past the last record starting before g1
+  const int64_t* ref_first;   // [n_ref+1] index of the first record of each reference
   const int32_t* iv_start;
   const int32_t* iv_end;
   const int64_t* iv_row;
   uint32_t* rows;             // n_rows * 11
   DeviceError* err;
   const uint8_t* qthr;        // [96] stitch: qthr[q0] = smallest q1 with qualSum[q0][q1] >= minBaseQual (255: none)
+  unsigned long long* dbg;    // diagnostic builds only (BP_STAMPS); NULL otherwise
   int64_t n_reads;
   int32_t n_windows;
   int32_t max_span;           // largest (clamped) span among submitted records

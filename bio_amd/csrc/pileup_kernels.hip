@@ -28,13 +28,47 @@
 
 namespace bp {
 
-constexpr int kW = 1024;       // window positions
-constexpr int kBlock = 512;    // threads per workgroup
+// Diagnostic build only (-DBP_STAMPS): per-window phase time stamps (s_memtime) written to
+// P.dbg; never compiled into the shipped library.
+#ifdef BP_STAMPS
+#define BP_STAMP(i)                                                                      \
+  do {                                                                                   \
+    if (P.dbg && (threadIdx.x & 63) == 0)                                                \
+      P.dbg[((uint64_t)item * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define BP_STAMP(i) do {} while (0)
+#endif
+
+// Tunables (overridable with -D for experiments; the defaults are what ships).
+#ifndef BP_W
+#define BP_W 1024
+#endif
+#ifndef BP_BLOCK
+#define BP_BLOCK 512
+#endif
+#ifndef BP_SEGCAP
+#define BP_SEGCAP 512
+#endif
+#ifndef BP_UNITCAP
+#define BP_UNITCAP 8192
+#endif
+#ifndef BP_DEPTH
+#define BP_DEPTH 4
+#endif
+#ifndef BP_WINS
+#define BP_WINS 8
+#endif
+#ifndef BP_MINWAVES
+#define BP_MINWAVES 4
+#endif
+constexpr int kW = BP_W;          // window positions
+constexpr int kBlock = BP_BLOCK;  // threads per workgroup
 constexpr int kPlanes = 12;    // 10 count planes + 2 depth-only planes
 
-__device__ __forceinline__ int strand_of(int32_t ref, int32_t mate_ref, uint32_t flags) {
+__device__ __forceinline__ int strand_of(bool mate_same_ref, uint32_t flags) {
   // pileup.GetStrand (pileup/common.go:94-114)
-  if (ref != mate_ref) return 0;
+  if (!mate_same_ref) return 0;
   uint32_t f = flags & 0xf0u;
   if (f == 0x60u || f == 0x90u) return 1;
   if (f == 0x50u || f == 0xa0u) return 2;
@@ -46,41 +80,25 @@ __device__ __forceinline__ int strand_of(int32_t ref, int32_t mate_ref, uint32_t
   return 0;
 }
 
-// Seq8ToEnumTable (pileup/common.go:66) times 2: 1,2,4,8 -> 0,2,4,6 ; everything else 8 (X).
-__device__ __forceinline__ uint32_t code2_of_nibble(uint32_t nib) {
-  // two bits per nibble value for the single-bit codes, validity mask 0x0116
-  uint32_t idx = (0x00030210u >> (nib * 2)) & 3u;  // nib 1->0, 2->1, 4->2, 8->3
-  uint32_t valid = (0x0116u >> nib) & 1u;
-  return valid ? idx * 2u : 8u;
-}
-
-__device__ __forceinline__ uint64_t sort_key(int32_t ref, int32_t pos) {
-  // unmapped (ref -1) sorts last, like biopb.Coord ordering
-  return ((uint64_t)(uint32_t)ref << 32) | (uint32_t)pos;
-}
-
 __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* win_r1) {
   int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= P.n_windows) return;
-  Window win = P.windows[w];
-  // first record with (ref,pos) >= (ref, g0 - max_span + 1)
+  const Window win = P.windows[w];
+  // records of the window's reference are the index range [lo, hi), sorted by pos
+  const int64_t lo = P.ref_first[win.ref_id], hi = P.ref_first[win.ref_id + 1];
+  // first record that can reach g0: pos >= g0 - max_span + 1
   int64_t lo_pos = (int64_t)win.g0 - P.max_span + 1;
   if (lo_pos < 0) lo_pos = 0;
-  uint64_t klo = sort_key(win.ref_id, (int32_t)lo_pos);
-  uint64_t khi = sort_key(win.ref_id, win.g1);
-  int64_t n = P.n_reads;
-  int64_t a = 0, b = n;
+  int64_t a = lo, b = hi;
   while (a < b) {
-    int64_t m = (a + b) >> 1;
-    const ReadCore& c = P.cores[m];
-    if (sort_key(c.ref_id, c.pos) < klo) a = m + 1; else b = m;
+    const int64_t m = (a + b) >> 1;
+    if ((int64_t)P.cores[m].pos < lo_pos) a = m + 1; else b = m;
   }
-  int64_t r0 = a;
-  b = n;
+  const int64_t r0 = a;
+  b = hi;
   while (a < b) {
-    int64_t m = (a + b) >> 1;
-    const ReadCore& c = P.cores[m];
-    if (sort_key(c.ref_id, c.pos) < khi) a = m + 1; else b = m;
+    const int64_t m = (a + b) >> 1;
+    if (P.cores[m].pos < win.g1) a = m + 1; else b = m;
   }
   win_r0[w] = (int32_t)r0;
   win_r1[w] = (int32_t)a;
@@ -88,9 +106,10 @@ __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* wi
 
 constexpr int kSub = kW / 8 + 4;     // padded sub-row: 8 residues x kSub
 constexpr int kStride = 8 * kSub;    // dwords per counter plane (multiple of 32)
-constexpr int kSegCap = 512;         // M-segments per round
-constexpr int kUnitCap = 8192;       // units (8 window positions of one segment) per round
-constexpr int kUnroll = 2;           // units in flight per lane
+constexpr int kSegCap = BP_SEGCAP;   // M-segments per round
+constexpr int kUnitCap = BP_UNITCAP; // units (8 window positions of one segment) per round
+constexpr int kDepth = BP_DEPTH;     // units in flight per lane (software pipeline depth)
+constexpr int kWinPerBlock = BP_WINS; // consecutive windows per workgroup
 
 // LDS histogram: 12 counter planes (A+ A- C+ C- G+ G- T+ T- X+ X- lowq+ lowq-), each plane
 // laid out by residue: position p = 8j + k lives at k*kSub + j.
@@ -172,271 +191,368 @@ __device__ __forceinline__ bool try_emit(BlockShared& S, int32_t sref, int32_t l
   return ok;
 }
 
+struct UnitLoad {
+  u32x3a qd;      // 12 bytes covering the unit's 8 quals
+  u32x2a sd;      // 8 bytes covering the unit's 8 packed bases
+  uint32_t seg;   // segment | active << 16
+  uint32_t jj;    // window unit (positions 8*jj .. 8*jj+7)
+};
+
+// Byte offsets, inside a record's payload, of the unit's first qual / first packed base.
+__device__ __forceinline__ void unit_offsets(uint32_t lseqnc, int32_t b0, int32_t& qoff, int32_t& soff) {
+  const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
+  const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
+  qoff = cigb + b0;
+  soff = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b0 >> 1);
+}
+
+// Loads are issued unconditionally (inactive lanes read the start of the payload buffer) so
+// that every issue is exactly two VMEM instructions and the counted vmcnt waits stay exact.
+__device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockShared& S, uint32_t t,
+                                           uint32_t T, UnitLoad& L) {
+  bool in = t < T;
+  uint32_t s = S.owner[in ? t : 0];
+  if (s == 0xffffu) { in = false; s = 0; }
+  const int32_t sref = S.s_ref[s];
+  const uint32_t lenq0 = S.s_lenq0[s];
+  const uint32_t lseqnc = S.s_lseqnc[s];
+  const uint32_t misc = S.s_misc[s];
+  const uint32_t bl = S.s_blob[s];
+  L.jj = in ? (misc >> 16) + (t - (misc & 0x7fffu)) : 0u;
+  L.seg = s | (in ? 0x10000u : 0u);
+  const int32_t b0 = (int32_t)(lenq0 >> 16) + ((int32_t)(L.jj * 8) - sref);
+  int32_t qoff, soff;
+  unit_offsets(lseqnc, b0, qoff, soff);
+  uint64_t rec_off = (uint64_t)bl * 8;
+  if (!in) { qoff = 0; soff = 0; rec_off = 0; }
+  const uint8_t* bp_ = P.blob + rec_off;
+  L.qd = *(const u32x3a*)(bp_ + (qoff & ~3));
+  L.sd = *(const u32x2a*)(bp_ + (soff & ~3));
+}
+
 template <bool STITCH, bool CLIP>
-__global__ __launch_bounds__(kBlock, 4) void pileup_kernel(KernelParams P) {
+__device__ __forceinline__ void process_unit(const KernelParams& P, BlockShared& B,
+                                             const UnitLoad& L, uint32_t wlen, int32_t g0) {
+  const bool in = (L.seg & 0x10000u) != 0;
+  const uint32_t s = L.seg & 0xffffu;
+  const int32_t sref = B.s_ref[s];
+  const uint32_t lenq0 = B.s_lenq0[s];
+  const uint32_t lseqnc = B.s_lseqnc[s];
+  const uint32_t misc = B.s_misc[s];
+  const int32_t Pw = (int32_t)(L.jj * 8);
+  const int32_t len = (int32_t)(lenq0 & 0xffffu);
+  const uint32_t lseq = lseqnc & 0xffffu;
+  const int32_t b0 = (int32_t)(lenq0 >> 16) + (Pw - sref);
+  int32_t qoff, soff;
+  unit_offsets(lseqnc, b0, qoff, soff);
+  // which of the 8 positions belong to the segment and the window
+  int32_t klo = sref - Pw;
+  klo = klo > 0 ? klo : 0;
+  klo = klo < 8 ? klo : 8;
+  int32_t e = sref + len;
+  e = e < (int32_t)wlen ? e : (int32_t)wlen;
+  int32_t khi = e - Pw;
+  khi = khi < 8 ? khi : 8;
+  khi = khi > 0 ? khi : 0;
+  uint32_t mask = ((1u << khi) - 1u) & ~((1u << klo) - 1u);
+  mask = in ? mask : 0u;
+  // 8 quals and 8 nibbles, realigned to the unit
+  const uint32_t qsh = (uint32_t)qoff & 3u;
+  const uint32_t qlo = __builtin_amdgcn_alignbyte(L.qd.y, L.qd.x, qsh);
+  const uint32_t qhi = __builtin_amdgcn_alignbyte(L.qd.z, L.qd.y, qsh);
+  // BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i
+  // (this is the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
+  const uint32_t x0 = ((L.sd.x & 0x0f0f0f0fu) << 4) | ((L.sd.x >> 4) & 0x0f0f0f0fu);
+  const uint32_t x1 = ((L.sd.y & 0x0f0f0f0fu) << 4) | ((L.sd.y >> 4) & 0x0f0f0f0fu);
+  const uint32_t noff = 2u * ((uint32_t)soff & 3u) + ((uint32_t)b0 & 1u);
+  const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, 4u * noff);
+  uint32_t sslot_u = (misc >> 15) & 1u;
+  const uint32_t minq = (uint32_t)P.min_base_qual;
+  const int32_t clip = P.clip;
+
+  int32_t mate_idx = -1;
+  bool second = false;
+  ReadCore mc;
+  int32_t myrec = 0;
+  if constexpr (STITCH) {
+    if (in) {
+      myrec = B.s_rec[s];
+      const int32_t m = P.mate[myrec];
+      if (m >= 0) {
+        mate_idx = m >> 1;
+        second = (m & 1) != 0;
+        mc = P.cores[mate_idx];
+        // the pair is counted on the strand of the read that found its mate
+        // (pileup.go:799-802); for the stored read that is the mate's strand
+        if (!second && !P.ignore_strand)
+          sslot_u = (uint32_t)(strand_of((mc.aux & AUX_MATE_SAME) != 0, mc.flags) - 1) & 1u;
+      }
+    }
+  }
+  uint32_t* const cb = B.cnt + sslot_u * kStride + L.jj;
+
+#ifndef BP_EXP_KMAX
+#define BP_EXP_KMAX 8
+#endif
+#pragma unroll
+  for (int k = 0; k < BP_EXP_KMAX; k++) {
+    const uint32_t nsh = (k == 0 ? (sw << 2) : (sw >> (4 * k - 2))) & 0x3cu;
+    // Seq8ToEnumTable (pileup/common.go:66) x2: nibble 1,2,4,8 -> 0,2,4,6; others 8 (X);
+    // and the plane a base failing the quality rule goes to: X stays X (always counted,
+    // pileup.go:227), others go to the depth-only plane 10.
+    const uint32_t c2 = (uint32_t)(0x8888888688848208ull >> nsh) & 15u;
+    const uint32_t cf = (uint32_t)(0x8888888a888a8aa8ull >> nsh) & 15u;
+    uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
+    if constexpr (CLIP) q = clipped_qual(q, b0 + k, (int32_t)lseq, clip);
+    uint32_t val = (mask >> k) & 1u;
+    uint32_t code = q >= minq ? c2 : cf;  // addBase (pileup.go:223-231)
+    if constexpr (STITCH) {
+      if (mate_idx >= 0 && val) {
+        const int32_t rp = Pw + k + g0;
+        const int32_t mi = read_index_at(mc, P.blob, rp);
+        if (mi >= 0) {
+          // both reads of the pair cover this position (pileup.go:409-430): Depth++ once,
+          // handled by the read that found its mate
+          if (!second) {
+            val = 0;
+          } else {
+            const uint8_t* mb = P.blob + (uint64_t)mc.blob * 8;
+            const uint32_t mcig = ((mc.n_cigar + 1u) & ~1u) * 4;
+            const uint32_t mU = ((uint32_t)mc.l_seq + 7) >> 3;
+            uint32_t mq = mb[mcig + mi];
+            const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
+            const uint32_t mnib = (mi & 1) ? (mbyte & 15u) : (mbyte >> 4);
+            if constexpr (CLIP) mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
+            if (mnib * 4 == nsh) {
+              if (q >= 96u || mq >= 96u) {
+                // qualPassTable index out of range: a Go runtime panic in the reference
+                atomicMin(&P.err->read, myrec);
+                val = 0;
+              } else {
+                code = mq >= (uint32_t)P.qthr[q] ? c2 : cf;
+              }
+            } else {
+              code = 8u;
+            }
+          }
+        }
+      }
+    }
+    atomicAdd(cb + code * kStride + k * kSub, val);
+  }
+}
+
+// Workgroup = kWinPerBlock consecutive windows, processed one after the other:
+//   phase 1  thread = record: read filters, CIGAR -> M-segments clipped to the window
+//   phase 2  thread = unit:   counts into the LDS planes
+//   flush    thread = position: Depth + Counts row to HBM, planes zeroed on the way out
+// The record cores of window i+1 are loaded while window i is in phase 2, so the only
+// exposed memory latency per window is that of the unit loads.
+template <bool STITCH, bool CLIP>
+__global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParams P) {
   __shared__ BlockShared S;
   const int tid = threadIdx.x;
 
-  // XCD-aware item order: workgroups b and b+8 share an XCD (and its L2); give each XCD a
-  // contiguous run of windows so records straddling two windows are re-read from L2.
+  // XCD-aware order: workgroups b and b+8 share an XCD (and its L2); give each XCD a
+  // contiguous run of windows so records straddling two workgroups are re-read from L2.
   const uint32_t nwg = gridDim.x;
   const uint32_t xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
   const uint32_t q8 = nwg >> 3, r8 = nwg & 7u;
-  const uint32_t item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
-
-  const Window win = P.windows[item];
-  const int32_t r0 = P.win_r0[item], r1 = P.win_r1[item];
-  const int32_t g0 = win.g0, g1 = win.g1;
-  const uint32_t wlen = (uint32_t)(g1 - g0);
+  const uint32_t blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+  const uint32_t w_first = blk * kWinPerBlock;
+  uint32_t w_last = w_first + kWinPerBlock;
+  if (w_last > (uint32_t)P.n_windows) w_last = (uint32_t)P.n_windows;
 
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
 
-  const int32_t clip = P.clip;
-  const uint32_t minq = (uint32_t)P.min_base_qual;
-
-  // per-thread record cursor
-  int32_t rec = r0 + tid;
-  bool have = false, keep = false;
-  uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, sslot = 0, aux = 0, span = 0;
-  int32_t rr = 0, qq = 0;
-
-  for (;;) {
-    if (tid == 0) {
-      S.n_seg = 0;
-      S.n_units = 0;
-    }
-    __syncthreads();
-    // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
-    if (rec < r1) {
-      if (!have) {
-        const uint4* cp = (const uint4*)(P.cores + rec);
-        const uint4 c0 = cp[0], c1 = cp[1];
-        const int32_t pos = (int32_t)c0.x;
-        const int32_t ref_id = (int32_t)c0.y, mate_ref = (int32_t)c0.w;
-        const uint32_t flags = c1.x & 0xffffu, mapq = (c1.x >> 16) & 0xffu;
-        aux = c1.x >> 24;
-        n_cigar = c1.y & 0xffffu;
-        span = c1.y >> 16;
-        blob = c1.w;
-        lseqnc = (c1.z & 0xffffu) | (n_cigar << 16);
-        const int strand = strand_of(ref_id, mate_ref, flags);
-        // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
-        keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
-        // strand filters (pileup.go:717-729)
-        if (P.strand_req != 0) keep = keep && strand == P.strand_req;
-        else keep = keep && (strand != 0 || P.ignore_strand);
-        keep = keep && ref_id == win.ref_id && pos < g1 && (int64_t)pos + span > (int64_t)g0;
-        sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
-        c_cur = 0;
-        rr = pos - g0;
-        qq = 0;
-        have = true;
-      }
-      bool done = true;
-      if (keep) {
-        if (aux & AUX_SIMPLE) {
-          done = try_emit(S, rr, (int32_t)span, 0, wlen, blob, lseqnc, sslot, rec);
-        } else {
-          const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
-          while (c_cur < n_cigar) {
-            const uint32_t op = cg[c_cur] & 15u;
-            const int32_t len = (int32_t)(cg[c_cur] >> 4);
-            if (op == 0) {
-              if (!try_emit(S, rr, len, qq, wlen, blob, lseqnc, sslot, rec)) {
-                done = false;
-                break;
-              }
-              rr += len; qq += len;
-            } else if (op == 1 || op == 4) {
-              qq += len;
-            } else if (op == 2 || op == 3) {
-              rr += len;
-            } else if (op != 5) {
-              break;  // host rejected reachable bad ops (pileup.go:355-359)
-            }
-            c_cur++;
-            if (rr >= (int32_t)wlen) break;
-          }
-        }
-      }
-      if (done) {
-        rec += kBlock;
-        have = false;
-      }
-    }
-    const int pending = rec < r1;
-    __syncthreads();
-
-    // ---- phase 2: thread = unit (8 window positions of one segment)
-    const uint32_t T = S.n_units < (uint32_t)kUnitCap ? S.n_units : (uint32_t)kUnitCap;
-    for (uint32_t t0 = tid; t0 < T; t0 += kBlock * kUnroll) {
-      u32x3a qd[kUnroll];
-      u32x2a sd[kUnroll];
-      int32_t sref[kUnroll], b0[kUnroll];
-      uint32_t lenq0[kUnroll], lseqnc_u[kUnroll], jj[kUnroll], sl[kUnroll], seg[kUnroll];
-      bool act[kUnroll];
-#pragma unroll
-      for (int u = 0; u < kUnroll; u++) {
-        const uint32_t t = t0 + (uint32_t)kBlock * u;
-        act[u] = false;
-        seg[u] = 0;
-        if (t < T) {
-          const uint32_t s = S.owner[t];
-          if (s != 0xffffu) {
-            act[u] = true;
-            seg[u] = s;
-            sref[u] = S.s_ref[s];
-            lenq0[u] = S.s_lenq0[s];
-            lseqnc_u[u] = S.s_lseqnc[s];
-            const uint32_t misc = S.s_misc[s];
-            const uint32_t bl = S.s_blob[s];
-            sl[u] = (misc >> 15) & 1u;
-            jj[u] = (misc >> 16) + (t - (misc & 0x7fffu));
-            const int32_t Pw = (int32_t)(jj[u] * 8);
-            b0[u] = (int32_t)(lenq0[u] >> 16) + (Pw - sref[u]);
-            const uint32_t nc = lseqnc_u[u] >> 16, lseq = lseqnc_u[u] & 0xffffu;
-            const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
-            const int32_t qoff = cigb + b0[u];
-            const int32_t soff = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b0[u] >> 1);
-            const uint8_t* bp_ = P.blob + (uint64_t)bl * 8;
-            qd[u] = *(const u32x3a*)(bp_ + (qoff & ~3));
-            sd[u] = *(const u32x2a*)(bp_ + (soff & ~3));
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; u++) {
-        if (!act[u]) continue;
-        const int32_t Pw = (int32_t)(jj[u] * 8);
-        const int32_t len = (int32_t)(lenq0[u] & 0xffffu);
-        const uint32_t nc = lseqnc_u[u] >> 16, lseq = lseqnc_u[u] & 0xffffu;
-        const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
-        const int32_t qoff = cigb + b0[u];
-        const int32_t soff = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b0[u] >> 1);
-        // which of the 8 positions belong to the segment and the window
-        int32_t klo = sref[u] - Pw;
-        klo = klo > 0 ? klo : 0;
-        int32_t e = sref[u] + len;
-        e = e < (int32_t)wlen ? e : (int32_t)wlen;
-        int32_t khi = e - Pw;
-        khi = khi < 8 ? khi : 8;
-        uint32_t mask = ((1u << khi) - 1u) & ~((1u << klo) - 1u);
-        // 8 quals and 8 nibbles, realigned to the unit
-        const uint32_t qsh = (uint32_t)qoff & 3u;
-        const uint32_t qlo = __builtin_amdgcn_alignbyte(qd[u].y, qd[u].x, qsh);
-        const uint32_t qhi = __builtin_amdgcn_alignbyte(qd[u].z, qd[u].y, qsh);
-        // BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i
-        // (this is the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
-        const uint32_t x0 = ((sd[u].x & 0x0f0f0f0fu) << 4) | ((sd[u].x >> 4) & 0x0f0f0f0fu);
-        const uint32_t x1 = ((sd[u].y & 0x0f0f0f0fu) << 4) | ((sd[u].y >> 4) & 0x0f0f0f0fu);
-        const uint32_t noff = 2u * ((uint32_t)soff & 3u) + ((uint32_t)b0[u] & 1u);
-        const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, 4u * noff);
-        uint32_t sslot_u = sl[u];
-
-        int32_t mate_idx = -1;
-        bool second = false;
-        ReadCore mc;
-        int32_t myrec = 0;
-        if constexpr (STITCH) {
-          myrec = S.s_rec[seg[u]];
-          const int32_t m = P.mate[myrec];
-          if (m >= 0) {
-            mate_idx = m >> 1;
-            second = (m & 1) != 0;
-            mc = P.cores[mate_idx];
-            // the pair is counted on the strand of the read that found its mate
-            // (pileup.go:799-802); for the stored read that is the mate's strand
-            if (!second && !P.ignore_strand)
-              sslot_u = (uint32_t)(strand_of(mc.ref_id, mc.mate_ref_id, mc.flags) - 1) & 1u;
-          }
-        }
-        uint32_t* const cb = S.cnt + sslot_u * kStride + jj[u];
-
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const uint32_t nsh = (k == 0 ? (sw << 2) : (sw >> (4 * k - 2))) & 0x3cu;
-          // Seq8ToEnumTable (pileup/common.go:66) x2: nibble 1,2,4,8 -> 0,2,4,6; others 8 (X);
-          // and the plane a base failing the quality rule goes to: X stays X (always counted,
-          // pileup.go:227), others go to the depth-only plane 10.
-          const uint32_t c2 = (uint32_t)(0x8888888688848208ull >> nsh) & 15u;
-          const uint32_t cf = (uint32_t)(0x8888888a888a8aa8ull >> nsh) & 15u;
-          uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
-          if constexpr (CLIP) q = clipped_qual(q, b0[u] + k, (int32_t)lseq, clip);
-          uint32_t val = (mask >> k) & 1u;
-          uint32_t code;
-          if constexpr (STITCH) {
-            code = q >= minq ? c2 : cf;
-            if (mate_idx >= 0 && val) {
-              const int32_t rp = Pw + k + g0;
-              const int32_t mi = read_index_at(mc, P.blob, rp);
-              if (mi >= 0) {
-                // both reads of the pair cover this position (pileup.go:409-430): Depth++ once,
-                // handled by the read that found its mate
-                if (!second) {
-                  val = 0;
-                } else {
-                  const uint8_t* mb = P.blob + (uint64_t)mc.blob * 8;
-                  const uint32_t mcig = ((mc.n_cigar + 1u) & ~1u) * 4;
-                  const uint32_t mU = (mc.l_seq + 7) >> 3;
-                  uint32_t mq = mb[mcig + mi];
-                  const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
-                  const uint32_t mnib = (mi & 1) ? (mbyte & 15u) : (mbyte >> 4);
-                  if constexpr (CLIP) mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
-                  if (mnib * 4 == nsh) {
-                    if (q >= 96u || mq >= 96u) {
-                      // qualPassTable index out of range: a Go runtime panic in the reference
-                      atomicMin(&P.err->read, myrec);
-                      val = 0;
-                    } else {
-                      code = mq >= (uint32_t)P.qthr[q] ? c2 : cf;
-                    }
-                  } else {
-                    code = 8u;
-                  }
-                }
-              }
-            }
-          } else {
-            // addBase (pileup.go:223-231)
-            code = q >= minq ? c2 : cf;
-          }
-          atomicAdd(cb + code * kStride + k * kSub, val);
-        }
-      }
-    }
-    if (!__syncthreads_or(pending)) break;
+  // prefetched core of this thread's first record of the upcoming window
+  int32_t n_r0 = P.win_r0[w_first], n_r1 = P.win_r1[w_first];
+  uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0;
+  if (n_r0 + tid < n_r1) {
+    const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
+    pc0 = cp[0];
+    pc1 = cp[1];
   }
 
-  // ---- flush: one lane per position; Depth = sum of the 12 planes (pileup.go:518-570)
-  for (uint32_t p = tid; p < wlen; p += kBlock) {
-    uint32_t v[kPlanes];
-    uint32_t d = 0;
-#pragma unroll
-    for (int c = 0; c < kPlanes; c++) {
-      v[c] = S.cnt[c * kStride + (p & 7u) * kSub + (p >> 3)];
-      d += v[c];
-    }
-    int64_t R;
-    if (win.full) {
-      R = win.row_base + p;
-    } else {
-      const int32_t gp = g0 + (int32_t)p;
-      uint32_t a = win.iv_lo, b = win.iv_hi;  // last interval with start <= gp
-      while (b - a > 1) {
-        const uint32_t m = (a + b) >> 1;
-        if (P.iv_start[m] <= gp) a = m; else b = m;
+  for (uint32_t item = w_first; item < w_last; item++) {
+    const Window win = P.windows[item];
+    const int32_t r0 = n_r0, r1 = n_r1;
+    const int32_t g0 = win.g0, g1 = win.g1;
+    const uint32_t wlen = (uint32_t)(g1 - g0);
+    BP_STAMP(0);
+
+    // per-thread record cursor
+    int32_t rec = r0 + tid;
+    bool have = false, keep = false, prefetched = true, next_issued = false;
+    uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, sslot = 0, aux = 0, span = 0;
+    uint32_t cg0 = 0, cg1 = 0, cg2 = 0;
+    int32_t rr = 0, qq = 0;
+    uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
+
+    for (;;) {
+      if (tid == 0) {
+        S.n_seg = 0;
+        S.n_units = 0;
       }
-      const int32_t is = P.iv_start[a];
-      if (gp < is || gp >= P.iv_end[a]) continue;  // not a BED position
-      R = P.iv_row[a] + (gp - is);
+      __syncthreads();
+      BP_STAMP(1);
+      // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
+      if (rec < r1) {
+        if (!have) {
+          uint4 c0 = pc0, c1 = pc1;
+          if (!prefetched) {
+            const uint4* cp = (const uint4*)(P.cores + rec);
+            c0 = cp[0];
+            c1 = cp[1];
+          }
+          const int32_t pos = (int32_t)c0.x;
+          const uint32_t flags = c0.y & 0xffffu, mapq = (c0.y >> 16) & 0xffu;
+          aux = c0.y >> 24;
+          n_cigar = c0.z & 0xffffu;
+          span = c0.z >> 16;
+          const uint32_t l_seq = c0.w & 0xffffu;
+          blob = c1.x;
+          cg0 = c1.y; cg1 = c1.z; cg2 = c1.w;
+          lseqnc = l_seq | (n_cigar << 16);
+          const int strand = strand_of((aux & AUX_MATE_SAME) != 0, flags);
+          // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
+          keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
+          // strand filters (pileup.go:717-729)
+          if (P.strand_req != 0) keep = keep && strand == P.strand_req;
+          else keep = keep && (strand != 0 || P.ignore_strand);
+          keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
+          sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
+          c_cur = 0;
+          rr = pos - g0;
+          qq = 0;
+          have = true;
+        }
+        bool done = true;
+        if (keep) {
+          if (aux & AUX_SIMPLE) {
+            done = try_emit(S, rr, (int32_t)span, 0, wlen, blob, lseqnc, sslot, rec);
+          } else {
+            const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
+            while (c_cur < n_cigar) {
+              // the first three ops travel in the core; longer CIGARs continue in the payload
+              const uint32_t cop = c_cur == 0 ? cg0 : c_cur == 1 ? cg1 : c_cur == 2 ? cg2 : cg[c_cur];
+              const uint32_t op = cop & 15u;
+              const int32_t len = (int32_t)(cop >> 4);
+              if (op == 0) {
+                if (!try_emit(S, rr, len, qq, wlen, blob, lseqnc, sslot, rec)) {
+                  done = false;
+                  break;
+                }
+                rr += len; qq += len;
+              } else if (op == 1 || op == 4) {
+                qq += len;
+              } else if (op == 2 || op == 3) {
+                rr += len;
+              } else if (op != 5) {
+                break;  // host rejected reachable bad ops (pileup.go:355-359)
+              }
+              c_cur++;
+              if (rr >= (int32_t)wlen) break;
+            }
+          }
+        }
+        if (done) {
+          rec += kBlock;
+          have = false;
+          prefetched = false;
+        }
+      }
+      const int pending = rec < r1;
+      BP_STAMP(2);
+      __syncthreads();
+      BP_STAMP(3);
+
+      // ---- prefetch for the next window: its record range and this thread's first core
+      if (!next_issued) {
+        next_issued = true;
+        if (item + 1 < w_last) {
+          n_r0 = P.win_r0[item + 1];
+          n_r1 = P.win_r1[item + 1];
+          if (n_r0 + tid < n_r1) {
+            const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
+            nc0 = cp[0];
+            nc1 = cp[1];
+          }
+        }
+      }
+
+      // ---- phase 2: thread = unit (8 window positions of one segment); kDepth units in
+      // flight per lane
+      const uint32_t T = S.n_units < (uint32_t)kUnitCap ? S.n_units : (uint32_t)kUnitCap;
+      const uint32_t wbase = (uint32_t)tid & ~63u;  // first unit slot of this wave in a sweep
+      if (wbase < T) {
+        UnitLoad L[kDepth];
+        uint32_t t = (uint32_t)tid;
+#pragma unroll
+        for (int d = 0; d < kDepth; d++) {
+          issue_unit(P, S, t, T, L[d]);
+          t += kBlock;
+        }
+        for (uint32_t tb = wbase; tb < T; tb += kBlock * kDepth) {
+#pragma unroll
+          for (int d = 0; d < kDepth; d++) {
+            if (tb + (uint32_t)kBlock * d < T) {  // wave-uniform
+              process_unit<STITCH, CLIP>(P, S, L[d], wlen, g0);
+              issue_unit(P, S, t, T, L[d]);
+            }
+            t += kBlock;
+          }
+        }
+      }
+      BP_STAMP(4);
+      if (!__syncthreads_or(pending)) break;
     }
-    uint32_t* out = P.rows + R * 11;
-    u32x4a o0 = {d, v[0], v[1], v[2]};
-    u32x4a o1 = {v[3], v[4], v[5], v[6]};
-    u32x3a o2 = {v[7], v[8], v[9]};
-    *(u32x4a*)(out) = o0;
-    *(u32x4a*)(out + 4) = o1;
-    *(u32x3a*)(out + 8) = o2;
+    BP_STAMP(5);
+
+    // ---- flush: one lane per position; Depth = sum of the 12 planes (pileup.go:518-570);
+    // the planes are zeroed as they are read, ready for the next window
+    for (uint32_t p = tid; p < (uint32_t)kW; p += kBlock) {
+      uint32_t v[kPlanes];
+      uint32_t d = 0;
+      uint32_t* const cp = S.cnt + (p & 7u) * kSub + (p >> 3);
+#pragma unroll
+      for (int c = 0; c < kPlanes; c++) {
+        v[c] = cp[c * kStride];
+        d += v[c];
+      }
+      if (d != 0) {
+#pragma unroll
+        for (int c = 0; c < kPlanes; c++) cp[c * kStride] = 0;
+      }
+      if (p >= wlen) continue;
+      int64_t R;
+      if (win.full) {
+        R = win.row_base + p;
+      } else {
+        const int32_t gp = g0 + (int32_t)p;
+        uint32_t a = win.iv_lo, b = win.iv_hi;  // last interval with start <= gp
+        while (b - a > 1) {
+          const uint32_t m = (a + b) >> 1;
+          if (P.iv_start[m] <= gp) a = m; else b = m;
+        }
+        const int32_t is = P.iv_start[a];
+        if (gp < is || gp >= P.iv_end[a]) continue;  // not a BED position
+        R = P.iv_row[a] + (gp - is);
+      }
+      uint32_t* out = P.rows + R * 11;
+#ifdef BP_EXP_NOFLUSH
+      if (d != 0x7fffffffu) continue;
+#endif
+      u32x4a o0 = {d, v[0], v[1], v[2]};
+      u32x4a o1 = {v[3], v[4], v[5], v[6]};
+      u32x3a o2 = {v[7], v[8], v[9]};
+      *(u32x4a*)(out) = o0;
+      *(u32x4a*)(out + 4) = o1;
+      *(u32x3a*)(out + 8) = o2;
+    }
+    BP_STAMP(6);
+    pc0 = nc0;
+    pc1 = nc1;
   }
 }
 
@@ -472,7 +588,7 @@ void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s)
 
 void launch_pileup(const KernelParams& P, hipStream_t s) {
   if (P.n_windows == 0) return;
-  const dim3 g(P.n_windows), b(kBlock);
+  const dim3 g((P.n_windows + kWinPerBlock - 1) / kWinPerBlock), b(kBlock);
   const bool clip = P.clip > 0;
   if (P.stitch) {
     if (clip) hipLaunchKernelGGL((pileup_kernel<true, true>), g, b, 0, s, P);

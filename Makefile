@@ -31,4 +31,4 @@ clean:
 # diagnostic build with in-kernel phase stamps (never shipped; see tools/phase_stamps.py)
 stamps: bio_amd/libbiopileup_stamps.so
 bio_amd/libbiopileup_stamps.so: $(LIB_SRCS) $(LIB_HDRS)
-	$(HIPCC) $(HIPFLAGS) -DBP_STAMPS -shared -o $@ $(LIB_SRCS) -lz -lpthread
+	$(HIPCC) $(HIPFLAGS) -DBP_STAMPS $(STAMPFLAGS) -shared -o $@ $(LIB_SRCS) -lz -lpthread

@@ -680,8 +680,8 @@ int bp_compute(bp_handle* h) {
   P.qthr = (const uint8_t*)h->d_qthr.p;
   P.dbg = nullptr;
 #ifdef BP_STAMPS
-  if (int rc = ensure(h, h->d_dbg, h->windows.size() * 8 * 8 * 8 + 256, 0)) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->d_dbg.p, 0, h->windows.size() * 8 * 8 * 8, h->stream));
+  if (int rc = ensure(h, h->d_dbg, h->windows.size() * 8 * (8 * 8 + 8 * 4) + 256, 0)) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_dbg.p, 0, h->windows.size() * 8 * (8 * 8 + 8 * 4), h->stream));
   P.dbg = (unsigned long long*)h->d_dbg.p;
 #endif
   P.n_reads = h->n_reads;

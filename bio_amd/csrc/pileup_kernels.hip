@@ -128,7 +128,8 @@ struct __align__(16) BlockShared {
   uint32_t s_misc[kSegCap];     // first unit slot | strand slot << 15 | first window unit << 16
   int32_t s_rec[kSegCap];       // record index (stitch)
   uint16_t owner[kUnitCap];     // unit slot -> segment
-  uint32_t n_seg, n_units;
+  unsigned long long n_alloc;   // segments << 32 | units handed out this round
+  uint32_t pad_[2];
 };
 
 // Reference position -> read index of record `c` (mate lookup for the overlap rule).
@@ -164,31 +165,51 @@ typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
 
-// Admit one M-segment into the round's list.  Returns false when the round is full: the
+// Admit one M-segment per lane into the round's list; called by every lane of the wave
+// (want = this lane has a segment).  Slots are handed out with a wave prefix sum and ONE
+// LDS atomic per wave on a packed (segments << 16 | units) counter, so unit slots grow with
+// the segment index.  Returns false for a lane whose segment did not fit this round: the
 // caller keeps its cursor and retries next round.
-__device__ __forceinline__ bool try_emit(BlockShared& S, int32_t sref, int32_t len, int32_t q0,
-                                         uint32_t wlen, uint32_t blob, uint32_t lseqnc,
-                                         uint32_t sslot, int32_t rec) {
+__device__ __forceinline__ bool emit_wave(BlockShared& S, bool want, int32_t sref, int32_t len,
+                                          int32_t q0, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
+                                          uint32_t sslot, int32_t rec) {
+  const int lane = threadIdx.x & 63;
   const int32_t s1 = sref > 0 ? sref : 0;
   const int32_t e1 = (int64_t)sref + len < (int64_t)wlen ? sref + len : (int32_t)wlen;
-  if (e1 <= s1) return true;
-  const uint32_t jlo = (uint32_t)s1 >> 3, jhi = (uint32_t)(e1 - 1) >> 3;
-  const uint32_t U = jhi - jlo + 1;
-  const uint32_t idx = atomicAdd(&S.n_seg, 1u);
-  const uint32_t us = atomicAdd(&S.n_units, U);
-  const bool ok = idx < (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
-  if (ok) {
-    S.s_ref[idx] = sref;
-    S.s_lenq0[idx] = (uint32_t)len | ((uint32_t)q0 << 16);
-    S.s_blob[idx] = blob;
-    S.s_lseqnc[idx] = lseqnc;
-    S.s_misc[idx] = us | (sslot << 15) | (jlo << 16);
-    S.s_rec[idx] = rec;
-    for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
-  } else {
-    for (uint32_t i = us; i < us + U && i < (uint32_t)kUnitCap; i++) S.owner[i] = 0xffffu;
+  const bool real = want && e1 > s1;  // clipped-away segments need no slot
+  const uint32_t jlo = (uint32_t)s1 >> 3;
+  const uint32_t U = real ? (((uint32_t)(e1 - 1) >> 3) - jlo + 1) : 0u;
+  // inclusive prefix sums of (1, U) over the wave, packed as count << 16 | units
+  // (a wave adds at most 64 segments x 129 units: no carry between the fields)
+  uint32_t incl = real ? (0x10000u | U) : 0u;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= o) incl += v;
   }
-  return ok;
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+  unsigned long long base = 0;
+  if (lane == 0 && total != 0)
+    base = atomicAdd(&S.n_alloc, ((unsigned long long)(total >> 16) << 32) | (total & 0xffffu));
+  const uint32_t base_u = (uint32_t)__shfl((int)(uint32_t)base, 0);
+  const uint32_t base_s = (uint32_t)__shfl((int)(uint32_t)(base >> 32), 0);
+  const uint32_t excl = incl - (real ? (0x10000u | U) : 0u);
+  const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
+  const bool ok = idx < (uint32_t)kSegCap && us < (uint32_t)kUnitCap && us + U <= (uint32_t)kUnitCap;
+  if (real) {
+    if (ok) {
+      S.s_ref[idx] = sref;
+      S.s_lenq0[idx] = (uint32_t)len | ((uint32_t)q0 << 16);
+      S.s_blob[idx] = blob;
+      S.s_lseqnc[idx] = lseqnc;
+      S.s_misc[idx] = us | (sslot << 15) | (jlo << 16);
+      S.s_rec[idx] = rec;
+      for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
+    } else {
+      for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
+    }
+  }
+  return ok || !real;
 }
 
 struct UnitLoad {
@@ -365,8 +386,16 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
 
-  // prefetched core of this thread's first record of the upcoming window
+  // Everything a window needs from global memory before its unit loads is fetched one
+  // window ahead (record range two ahead): window descriptor, record range, this thread's
+  // first record core.
+  Window n_win = P.windows[w_first];
   int32_t n_r0 = P.win_r0[w_first], n_r1 = P.win_r1[w_first];
+  int32_t nn_r0 = 0, nn_r1 = 0;
+  if (w_first + 1 < w_last) {
+    nn_r0 = P.win_r0[w_first + 1];
+    nn_r1 = P.win_r1[w_first + 1];
+  }
   uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0;
   if (n_r0 + tid < n_r1) {
     const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
@@ -375,7 +404,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   }
 
   for (uint32_t item = w_first; item < w_last; item++) {
-    const Window win = P.windows[item];
+    const Window win = n_win;
     const int32_t r0 = n_r0, r1 = n_r1;
     const int32_t g0 = win.g0, g1 = win.g1;
     const uint32_t wlen = (uint32_t)(g1 - g0);
@@ -390,47 +419,50 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
 
     for (;;) {
-      if (tid == 0) {
-        S.n_seg = 0;
-        S.n_units = 0;
-      }
+      if (tid == 0) S.n_alloc = 0;
       __syncthreads();
       BP_STAMP(1);
       // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
-      if (rec < r1) {
-        if (!have) {
-          uint4 c0 = pc0, c1 = pc1;
-          if (!prefetched) {
-            const uint4* cp = (const uint4*)(P.cores + rec);
-            c0 = cp[0];
-            c1 = cp[1];
-          }
-          const int32_t pos = (int32_t)c0.x;
-          const uint32_t flags = c0.y & 0xffffu, mapq = (c0.y >> 16) & 0xffu;
-          aux = c0.y >> 24;
-          n_cigar = c0.z & 0xffffu;
-          span = c0.z >> 16;
-          const uint32_t l_seq = c0.w & 0xffffu;
-          blob = c1.x;
-          cg0 = c1.y; cg1 = c1.z; cg2 = c1.w;
-          lseqnc = l_seq | (n_cigar << 16);
-          const int strand = strand_of((aux & AUX_MATE_SAME) != 0, flags);
-          // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
-          keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
-          // strand filters (pileup.go:717-729)
-          if (P.strand_req != 0) keep = keep && strand == P.strand_req;
-          else keep = keep && (strand != 0 || P.ignore_strand);
-          keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
-          sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
-          c_cur = 0;
-          rr = pos - g0;
-          qq = 0;
-          have = true;
+      const bool has_rec = rec < r1;
+      if (has_rec && !have) {
+        uint4 c0 = pc0, c1 = pc1;
+        if (!prefetched) {
+          const uint4* cp = (const uint4*)(P.cores + rec);
+          c0 = cp[0];
+          c1 = cp[1];
         }
-        bool done = true;
-        if (keep) {
+        const int32_t pos = (int32_t)c0.x;
+        const uint32_t flags = c0.y & 0xffffu, mapq = (c0.y >> 16) & 0xffu;
+        aux = c0.y >> 24;
+        n_cigar = c0.z & 0xffffu;
+        span = c0.z >> 16;
+        const uint32_t l_seq = c0.w & 0xffffu;
+        blob = c1.x;
+        cg0 = c1.y; cg1 = c1.z; cg2 = c1.w;
+        lseqnc = l_seq | (n_cigar << 16);
+        const int strand = strand_of((aux & AUX_MATE_SAME) != 0, flags);
+        // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
+        keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
+        // strand filters (pileup.go:717-729)
+        if (P.strand_req != 0) keep = keep && strand == P.strand_req;
+        else keep = keep && (strand != 0 || P.ignore_strand);
+        keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
+        sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
+        c_cur = 0;
+        rr = pos - g0;
+        qq = 0;
+        have = true;
+      }
+      // CIGAR walk (pileup.go:275-363): every M op is one segment; the wave emits one segment
+      // per lane per step, all lanes together
+      bool more = has_rec && keep, failed = false;
+      for (;;) {
+        bool want = false;
+        int32_t seg_len = 0, seg_q0 = 0;
+        if (more) {
           if (aux & AUX_SIMPLE) {
-            done = try_emit(S, rr, (int32_t)span, 0, wlen, blob, lseqnc, sslot, rec);
+            want = true;
+            seg_len = (int32_t)span;
           } else {
             const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
             while (c_cur < n_cigar) {
@@ -439,53 +471,111 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
               const uint32_t op = cop & 15u;
               const int32_t len = (int32_t)(cop >> 4);
               if (op == 0) {
-                if (!try_emit(S, rr, len, qq, wlen, blob, lseqnc, sslot, rec)) {
-                  done = false;
-                  break;
-                }
-                rr += len; qq += len;
+                want = true;
+                seg_len = len;
+                seg_q0 = qq;
+                break;
               } else if (op == 1 || op == 4) {
                 qq += len;
               } else if (op == 2 || op == 3) {
                 rr += len;
               } else if (op != 5) {
-                break;  // host rejected reachable bad ops (pileup.go:355-359)
+                c_cur = n_cigar;  // host rejected reachable bad ops (pileup.go:355-359)
+                break;
               }
               c_cur++;
-              if (rr >= (int32_t)wlen) break;
+              if (rr >= (int32_t)wlen) c_cur = n_cigar;
             }
+            if (!want) more = false;
           }
         }
-        if (done) {
-          rec += kBlock;
-          have = false;
-          prefetched = false;
+        if (!__any(want)) break;
+        const bool ok = emit_wave(S, want, rr, seg_len, seg_q0, wlen, blob, lseqnc, sslot, rec);
+        if (want) {
+          if (!ok) {
+            failed = true;
+            more = false;
+          } else if (aux & AUX_SIMPLE) {
+            more = false;
+          } else {
+            rr += seg_len;
+            qq += seg_len;
+            c_cur++;
+            if (rr >= (int32_t)wlen) more = false;
+          }
         }
+      }
+      if (has_rec && !failed) {
+        rec += kBlock;
+        have = false;
+        prefetched = false;
       }
       const int pending = rec < r1;
       BP_STAMP(2);
       __syncthreads();
       BP_STAMP(3);
 
-      // ---- prefetch for the next window: its record range and this thread's first core
+      // ---- prefetch for the next window(s)
       if (!next_issued) {
         next_issued = true;
         if (item + 1 < w_last) {
-          n_r0 = P.win_r0[item + 1];
-          n_r1 = P.win_r1[item + 1];
+          n_r0 = nn_r0;
+          n_r1 = nn_r1;
+          n_win = P.windows[item + 1];
           if (n_r0 + tid < n_r1) {
             const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
             nc0 = cp[0];
             nc1 = cp[1];
+          }
+          if (item + 2 < w_last) {
+            nn_r0 = P.win_r0[item + 2];
+            nn_r1 = P.win_r1[item + 2];
           }
         }
       }
 
       // ---- phase 2: thread = unit (8 window positions of one segment); kDepth units in
       // flight per lane
-      const uint32_t T = S.n_units < (uint32_t)kUnitCap ? S.n_units : (uint32_t)kUnitCap;
-      const uint32_t wbase = (uint32_t)tid & ~63u;  // first unit slot of this wave in a sweep
-      if (wbase < T) {
+      const uint32_t n_alloc_u = (uint32_t)S.n_alloc;
+      const uint32_t T = n_alloc_u < (uint32_t)kUnitCap ? n_alloc_u : (uint32_t)kUnitCap;
+#ifdef BP_STAMPS_P2
+      const uint32_t wbase = (uint32_t)tid & ~63u;
+#endif
+#ifdef BP_STAMPS_P2
+      // diagnostic: serialise one unit at a time and time its three parts
+      {
+        unsigned long long a_issue = 0, a_wait = 0, a_proc = 0;
+        for (uint32_t tb = wbase; tb < T; tb += kBlock) {
+          UnitLoad L1;
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_sched_barrier(0);
+          issue_unit(P, S, tb + (tid & 63), T, L1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_sched_barrier(0);
+          process_unit<STITCH, CLIP>(P, S, L1, wlen, g0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+          a_issue += t1 - t0; a_wait += t2 - t1; a_proc += t3 - t2;
+        }
+        if (P.dbg && (tid & 63) == 0) {
+          unsigned long long* o = P.dbg + (unsigned long long)P.n_windows * 64 + ((uint64_t)item * (kBlock / 64) + (tid >> 6)) * 4;
+          o[0] = a_issue; o[1] = a_wait; o[2] = a_proc; o[3] = (T + kBlock - 1) / kBlock;
+        }
+      }
+#else
+      {
+        // Every thread runs n_it unit slots (block-uniform).  The steady-state loop has no
+        // branch in its body, so the compiler's counted vmcnt waits keep kDepth units' loads
+        // in flight; only the drain after the loop is conservative.
+        const uint32_t n_it = (T + kBlock - 1) / kBlock;
         UnitLoad L[kDepth];
         uint32_t t = (uint32_t)tid;
 #pragma unroll
@@ -493,17 +583,21 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           issue_unit(P, S, t, T, L[d]);
           t += kBlock;
         }
-        for (uint32_t tb = wbase; tb < T; tb += kBlock * kDepth) {
+        uint32_t it = 0;
+        for (; it + kDepth <= n_it; it += kDepth) {
 #pragma unroll
           for (int d = 0; d < kDepth; d++) {
-            if (tb + (uint32_t)kBlock * d < T) {  // wave-uniform
-              process_unit<STITCH, CLIP>(P, S, L[d], wlen, g0);
-              issue_unit(P, S, t, T, L[d]);
-            }
+            process_unit<STITCH, CLIP>(P, S, L[d], wlen, g0);
+            issue_unit(P, S, t, T, L[d]);
             t += kBlock;
           }
         }
+        const uint32_t rem = n_it - it;
+#pragma unroll
+        for (int d = 0; d < kDepth - 1; d++)
+          if ((uint32_t)d < rem) process_unit<STITCH, CLIP>(P, S, L[d], wlen, g0);
       }
+#endif
       BP_STAMP(4);
       if (!__syncthreads_or(pending)) break;
     }

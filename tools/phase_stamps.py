@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bio_amd import _abi, snp, synth  # noqa: E402
 
-_abi.LIB_PATH = os.path.join(ROOT, "bio_amd", "libbiopileup_stamps.so")
+_abi.LIB_PATH = os.environ.get("STAMPS_LIB") or os.path.join(ROOT, "bio_amd", "libbiopileup_stamps.so")
 L = int(float(sys.argv[1])) if len(sys.argv) > 1 else 40_000_000
 sb = synth.generate([(0, 0, L - 1000, 30.0)])
 rb = sb.to_record_batch()
@@ -36,5 +36,13 @@ for i, n in enumerate(names):
     d = st[:, :, i + 1] - st[:, :, i]
     print("  %-14s mean %.0f  (all waves)   wave0 mean %.0f  max-wave mean %.0f" % (
         n, d.mean(), d[:, 0].mean(), d.max(axis=1).mean()))
+if os.environ.get("P2"):
+    p2 = np.zeros((nw, 8, 4), np.uint64)
+    buf = np.zeros(nw * 64 + nw * 32, np.uint64)
+    assert lib.bp_debug_stamps(job.h, buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+    p2 = buf[nw * 64:].reshape(nw, 8, 4).astype(np.int64)
+    n = np.maximum(p2[:, :, 3], 1)
+    print("phase-2 per unit (serialised, depth 1): issue(LDS) %.0f  wait(vmem) %.0f  process %.0f cycles; units/thread %.1f" % (
+        (p2[:, :, 0] / n).mean(), (p2[:, :, 1] / n).mean(), (p2[:, :, 2] / n).mean(), p2[:, :, 3].mean()))
 span = st[:, :, 6].max() - st[:, :, 0].min()
 print("first start -> last end: %d ticks; sum(window totals)/span = %.1f concurrent windows" % (span, tot.sum() / span))

@@ -66,6 +66,36 @@ EXPORTS = [
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
 ]
 
+HOST_EXPORTS = [
+    "bio_pileup_default_opts", "bio_pileup_run", "bio_pileup_main", "bio_parse_region",
+    "bio_parse_cols", "bio_bed_load", "bio_bed_endpoints", "bio_bed_intersects", "bio_bed_free",
+    "bio_fasta_seq8", "bio_bam_scan",
+]
+
+
+class bio_pileup_opts(C.Structure):
+    """include/bio_pileup_host.h: snp.Opts"""
+    _fields_ = [
+        ("bed_path", C.c_char_p),
+        ("region", C.c_char_p),
+        ("bam_index_path", C.c_char_p),
+        ("clip", C.c_int32),
+        ("cols", C.c_char_p),
+        ("flag_exclude", C.c_int32),
+        ("mapq", C.c_int32),
+        ("max_read_len", C.c_int32),
+        ("max_read_span", C.c_int32),
+        ("min_bag_depth", C.c_int32),
+        ("min_base_qual", C.c_int32),
+        ("parallelism", C.c_int32),
+        ("per_strand", C.c_int32),
+        ("remove_sq", C.c_int32),
+        ("stitch", C.c_int32),
+        ("temp_dir", C.c_char_p),
+        ("device", C.c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -112,5 +142,32 @@ def load():
     lib.bp_last_error.restype = C.c_char_p
     lib.bp_destroy.argtypes = [H]
     lib.bp_destroy.restype = None
+    # include/bio_pileup_host.h
+    E = [C.c_char_p, C.c_size_t]
+    lib.bio_pileup_default_opts.argtypes = [C.POINTER(bio_pileup_opts)]
+    lib.bio_pileup_default_opts.restype = None
+    lib.bio_pileup_run.argtypes = [C.c_char_p] * 4 + [C.POINTER(bio_pileup_opts)] + E
+    lib.bio_pileup_run.restype = C.c_int
+    lib.bio_pileup_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    lib.bio_pileup_main.restype = C.c_int
+    lib.bio_parse_region.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32)] + E
+    lib.bio_parse_region.restype = C.c_int
+    lib.bio_parse_cols.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)] + E
+    lib.bio_parse_cols.restype = C.c_int
+    lib.bio_bed_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
+                                 C.POINTER(H)] + E
+    lib.bio_bed_load.restype = C.c_int
+    lib.bio_bed_endpoints.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    lib.bio_bed_endpoints.restype = C.c_int32
+    lib.bio_bed_intersects.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
+    lib.bio_bed_intersects.restype = C.c_int
+    lib.bio_bed_free.argtypes = [H]
+    lib.bio_bed_free.restype = None
+    lib.bio_fasta_seq8.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8), C.c_int64] + E
+    lib.bio_fasta_seq8.restype = C.c_int64
+    lib.bio_bam_scan.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_int32)] + E
+    lib.bio_bam_scan.restype = C.c_int
     _lib = lib
     return lib

@@ -1,0 +1,103 @@
+"""Minimal BAM / FASTA / BED writers for tests and end-to-end runs (public SAM-spec layout;
+the record block is the one gbam.Unmarshal decodes, encoding/bam/unmarshal.go:126-224).
+Writers only: reading is the native library's job (bio_amd/csrc/host/bam.cpp)."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+_BLOCK = 0xFF00
+
+
+def _bgzf_block(data, level):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = 18 + len(comp) + 8 - 1
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+class BgzfWriter:
+    def __init__(self, path, level=1):
+        self.f = open(path, "wb")
+        self.buf = bytearray()
+        self.level = level
+
+    def write(self, b):
+        self.buf += b
+        while len(self.buf) >= _BLOCK:
+            self.f.write(_bgzf_block(bytes(self.buf[:_BLOCK]), self.level))
+            del self.buf[:_BLOCK]
+
+    def close(self):
+        if self.buf:
+            self.f.write(_bgzf_block(bytes(self.buf), self.level))
+        self.f.write(_EOF)
+        self.f.close()
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def write_bam(path, ref_names, ref_lens, batch, names=None, aux=None, level=1):
+    """batch: bio_amd.records.RecordBatch (coordinate-sorted).  names: list of bytes/str per
+    record (default: batch names, else r<i>).  aux: optional list of raw aux byte strings."""
+    w = BgzfWriter(path, level)
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(
+        f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(ref_names, ref_lens))
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(ref_names))
+    for n, l in zip(ref_names, ref_lens):
+        nb = n.encode() + b"\0"
+        hdr += struct.pack("<i", len(nb)) + nb + struct.pack("<i", int(l))
+    w.write(hdr)
+    b = batch
+    have_names = names is None and b.name_off is not None and b.name is not None
+    for i in range(b.n):
+        if names is not None:
+            nm = names[i] if isinstance(names[i], bytes) else str(names[i]).encode()
+        elif have_names:
+            nm = bytes(b.name[int(b.name_off[i]):int(b.name_off[i + 1])])
+        else:
+            nm = b"r%d" % i
+        nm += b"\0"
+        nc, ls = int(b.n_cigar[i]), int(b.l_seq[i])
+        cig = b.cigar[int(b.cigar_off[i]):int(b.cigar_off[i]) + nc]
+        span = int(sum(int(c) >> 4 for c in cig if (int(c) & 15) in (0, 2, 3, 7, 8)))
+        pos = int(b.pos[i])
+        body = struct.pack("<iiBBHHHIiii", int(b.ref_id[i]), pos, len(nm), int(b.mapq[i]),
+                           _reg2bin(pos, pos + max(span, 1)), nc, int(b.flags[i]), ls,
+                           int(b.mate_ref_id[i]), int(b.mate_pos[i]), 0)
+        body += nm + np.asarray(cig, np.uint32).tobytes()
+        body += bytes(b.seq[int(b.seq_off[i]):int(b.seq_off[i]) + (ls + 1) // 2])
+        body += bytes(b.qual[int(b.qual_off[i]):int(b.qual_off[i]) + ls])
+        if aux is not None:
+            body += aux[i]
+        w.write(struct.pack("<i", len(body)) + body)
+    w.close()
+
+
+def write_fasta(path, names, seqs, width=60, gz=False):
+    """seqs: ASCII strings/bytes."""
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for n, s in zip(names, seqs):
+            if isinstance(s, str):
+                s = s.encode()
+            f.write(b">" + n.encode() + b" test contig\n")
+            for o in range(0, len(s), width):
+                f.write(s[o:o + width] + b"\n")
+
+
+def write_bed(path, intervals, ref_names, gz=False):
+    """intervals: list of (ref_id, start, end)"""
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for r, s, e in intervals:
+            f.write(f"{ref_names[r]}\t{s}\t{e}\ttarget\n".encode())

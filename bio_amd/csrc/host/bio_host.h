@@ -1,0 +1,169 @@
+// bio_host.h -- host-side layers around the device pileup: the C++ counterparts of the
+// reference packages that sit on either side of the hot path (SURVEY.md section 8 rows a2,
+// a16-a20).  Everything here is plain host code; counts are only ever produced by the HIP
+// path behind include/bio_pileup.h.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/bio_pileup.h"
+
+namespace bio {
+
+using PosType = int32_t;                      // interval.PosType (endpoint_index.go:52)
+constexpr PosType kPosTypeMax = 2147483647;   // interval.PosTypeMax
+
+// ---------------------------------------------------------------- interval (bedunion.go)
+struct Entry {  // interval.Entry (bedunion.go:581-585)
+  std::string ref_name;
+  PosType start0 = 0, end = 0;
+};
+
+// interval.ParseRegionString (bedunion.go:593-651).  Returns "" or the error text.
+std::string ParseRegionString(const std::string& region, Entry* out);
+
+// interval.BEDUnion restricted to what pileup uses: per-reference sorted endpoint arrays,
+// looked up by reference ID (bedunion.go:72-99).  `present[i]` distinguishes a reference the
+// BED never mentions (nil in Go) from one it mentions.
+struct BEDUnion {
+  std::vector<std::string> ref_names;
+  std::vector<std::vector<PosType>> id_map;
+  std::vector<uint8_t> present;
+
+  // NewBEDUnionFromPath (bedunion.go:563-578) + scanBEDUnion (:411-540); gzip transparent.
+  static std::string FromPath(const std::string& path, const std::vector<std::string>& ref_names,
+                              BEDUnion* out);
+  // NewBEDUnionFromEntries (bedunion.go:655-735)
+  static std::string FromEntries(const std::vector<Entry>& entries,
+                                 const std::vector<std::string>& ref_names, BEDUnion* out);
+  bool IntersectsByID(int ref, PosType start, PosType limit) const;  // bedunion.go:219-254
+  // Subset (bedunion.go:753-852) for a single-reference or multi-reference range.
+  BEDUnion Subset(int start_ref, PosType start_pos, int limit_ref, PosType limit_pos) const;
+  int64_t NumPositions() const;
+};
+
+// ---------------------------------------------------------------- encoding/bam (reader)
+struct BamHeader {
+  std::string text;
+  std::vector<std::string> ref_names;
+  std::vector<int32_t> ref_lens;
+};
+
+// Growable structure-of-arrays record batch; view() exposes it as a bp_record_batch.
+struct RecordBatchBuilder {
+  std::vector<int32_t> ref_id, pos, mate_ref_id, mate_pos;
+  std::vector<uint16_t> flags;
+  std::vector<uint8_t> mapq;
+  std::vector<uint32_t> n_cigar, l_seq;
+  std::vector<uint64_t> cigar_off, seq_off, qual_off, name_off;
+  std::vector<uint32_t> cigar;
+  std::vector<uint8_t> seq, qual, name;
+  bool keep_names = true;
+  int64_t size() const { return (int64_t)pos.size(); }
+  void clear();
+  bp_record_batch view();
+};
+
+// Sequential BGZF/BAM reader: header + alignment records in file order, decoded per
+// encoding/bam/unmarshal.go:126-224 / SAM spec 4.2.
+class BamReader {
+ public:
+  BamReader();
+  ~BamReader();
+  std::string Open(const std::string& path);
+  const BamHeader& header() const { return header_; }
+  // Decodes the next record into raw fields; returns 1 on a record, 0 at EOF, -1 on error
+  // (message in err()).
+  struct Raw {
+    int32_t ref_id, pos, mate_ref_id, mate_pos;
+    uint16_t flags, n_cigar;
+    uint8_t mapq;
+    uint32_t l_seq;
+    const char* name; uint32_t l_name;  // without the NUL
+    const uint32_t* cigar;
+    const uint8_t* seq; const uint8_t* qual;
+    const uint8_t* aux; uint32_t l_aux;
+  };
+  int Next(Raw* r);
+  const std::string& err() const { return err_; }
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+  BamHeader header_;
+  std::string err_;
+};
+
+// Integer value of a 2-character aux tag (A/c/C/s/S/i/I types); returns false if absent.
+bool AuxInt(const uint8_t* aux, uint32_t l_aux, const char tag[2], int64_t* out);
+
+// ---------------------------------------------------------------- encoding/fasta + pileup.LoadFa
+// fasta.New eager loader with Seq8 encoding (fasta.go:120-175, biosimd_amd64.go:471-511):
+// A/a 1, C/c 2, G/g 4, T/t 8, everything else 15.
+struct Fasta {
+  std::vector<std::string> names;
+  std::vector<std::string> seqs;  // Seq8 bytes
+  int Find(const std::string& name) const;
+};
+std::string LoadFaSeq8(const std::string& path, Fasta* out);
+// pileup.FaToStringSlice (pileup/common.go:194-225)
+std::string FaToStringSlice(const Fasta& fa, const BamHeader& h, std::vector<const std::string*>* out,
+                            std::string* warnings);
+
+// ---------------------------------------------------------------- pileup/snp
+struct Opts {  // snp.Opts / snp.DefaultOpts (pileup/snp/pileup.go:36-68)
+  std::string BedPath, Region, BamIndexPath;
+  int Clip = 0;
+  std::string Cols;
+  int FlagExclude = 0xf00;
+  int Mapq = 60;
+  int MaxReadLen = 500;
+  int MaxReadSpan = 511;
+  int MinBagDepth = 0;
+  int MinBaseQual = 0;
+  int Parallelism = 0;
+  bool PerStrand = false;
+  bool RemoveSq = false;
+  bool Stitch = false;
+  std::string TempDir;
+  int Device = 0;  // HIP device ordinal (no counterpart in the reference)
+};
+
+// Column-set bits (pileup.go:134-157) and pileup.ParseCols (pileup/common.go:118-166).
+enum {
+  kColDpRef = 1, kColDpAlt = 2, kColEndDists = 4, kColQuals = 8, kColFraglens = 16,
+  kColStrands = 32, kColHighQ = 64, kColLowQ = 128
+};
+std::string ParseCols(const std::string& cols, int default_bitset, int* out);
+
+// snp.Pileup (pileup.go:970-1130).  Returns "" or the error text (the CLI turns it into a
+// panic-style exit like main.go:94-96).
+std::string Pileup(const std::string& xampath, const std::string& fapath, const std::string& format,
+                   const std::string& out_prefix, const Opts& opts);
+
+// cmd/bio-pileup main (main.go:60-98): flag parsing + Pileup.  Returns the process exit code.
+int BioPileupMain(int argc, char** argv);
+
+// ---------------------------------------------------------------- output (output.go)
+// Row sink used by Pileup: rows arrive in ascending (ref,pos) order.
+class RowWriter {
+ public:
+  virtual ~RowWriter() {}
+  virtual std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n) = 0;
+  virtual std::string Close() = 0;
+};
+// ConvertPileupRowsToTSV (output.go:42-300): <prefix>.ref.tsv[.gz] + <prefix>.alt.tsv[.gz]
+std::unique_ptr<RowWriter> NewTsvWriter(const std::string& main_path, int col_bitset, bool bgzip,
+                                        const std::vector<std::string>& ref_names,
+                                        const std::vector<const std::string*>& ref_seqs, std::string* err);
+// ConvertPileupRowsToBasestrandTSV (output.go:376-575): <prefix>.basestrand.tsv[.gz]
+std::unique_ptr<RowWriter> NewBasestrandTsvWriter(const std::string& main_path, int col_bitset, bool bgzip,
+                                                  const std::vector<std::string>& ref_names,
+                                                  const std::vector<const std::string*>& ref_seqs,
+                                                  std::string* err);
+
+}  // namespace bio

@@ -1,0 +1,288 @@
+// output.cpp -- final-format writers (reference: pileup/snp/output.go).  The reference renders
+// PileupRow temp files; here rows come straight from the device in (ref,pos) order.
+//
+// tsv.Writer (grailbio/base, not in the reference tree) is restated from its observable
+// behaviour in cmd/bio-pileup/testdata/*.expected: every Write* appends the field and a tab,
+// EndLine turns the trailing tab into a newline.
+#include <zlib.h>
+
+#include <cstring>
+#include <thread>
+
+#include "bio_host.h"
+
+namespace bio {
+
+namespace {
+
+const char kSeq8ToASCII[16] = {'=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'};  // common.go:72
+const uint8_t kSeq8ToEnum[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};                                 // common.go:66
+const char kEnumToASCII[5] = {'A', 'C', 'G', 'T', 'N'};                                                           // common.go:69
+
+// Byte sink: plain file, or BGZF (public SAM-spec container: <=64 KiB gzip members with a
+// BC extra subfield and an empty EOF member), compressed a batch of blocks at a time.
+class Sink {
+ public:
+  Sink(bool bgzf) : bgzf_(bgzf) {}
+  ~Sink() { if (f_) fclose(f_); }
+  std::string Open(const std::string& path) {
+    path_ = path;
+    f_ = fopen(path.c_str(), "wb");
+    if (!f_) return "open " + path + ": cannot create";
+    setvbuf(f_, nullptr, _IOFBF, 4 << 20);
+    return "";
+  }
+  std::string Write(const char* p, size_t n) {
+    if (!bgzf_) {
+      if (fwrite(p, 1, n, f_) != n) return "write " + path_ + ": short write";
+      return "";
+    }
+    pend_.append(p, n);
+    if (pend_.size() >= kBlock * kBatch) return Compress(false);
+    return "";
+  }
+  std::string Close() {
+    std::string err;
+    if (bgzf_) {
+      err = Compress(true);
+      static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
+                                      0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (err.empty() && fwrite(eof, 1, 28, f_) != 28) err = "write " + path_ + ": short write";
+    }
+    if (f_ && fclose(f_) != 0 && err.empty()) err = "close " + path_ + ": failed";
+    f_ = nullptr;
+    return err;
+  }
+
+ private:
+  static constexpr size_t kBlock = 0xff00;
+  static constexpr size_t kBatch = 32;
+
+  std::string Compress(bool all) {
+    size_t nblk = all ? (pend_.size() + kBlock - 1) / kBlock : pend_.size() / kBlock;
+    if (nblk == 0) return "";
+    std::vector<std::string> out(nblk);
+    std::vector<int> bad(nblk, 0);
+    auto work = [&](size_t t, size_t nt) {
+      for (size_t b = t; b < nblk; b += nt) {
+        const size_t off = b * kBlock, len = std::min(kBlock, pend_.size() - off);
+        std::string& o = out[b];
+        o.resize(18 + compressBound((uLong)len) + 8);
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[b] = 1; continue; }
+        zs.next_in = (Bytef*)pend_.data() + off;
+        zs.avail_in = (uInt)len;
+        zs.next_out = (Bytef*)o.data() + 18;
+        zs.avail_out = (uInt)(o.size() - 18);
+        int rc = deflate(&zs, Z_FINISH);
+        size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) { bad[b] = 1; continue; }
+        uint8_t* h = (uint8_t*)o.data();
+        const uint8_t hd[12] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0};
+        memcpy(h, hd, 12);
+        h[12] = 'B'; h[13] = 'C'; h[14] = 2; h[15] = 0;
+        const size_t bsize = 18 + clen + 8 - 1;
+        h[16] = (uint8_t)(bsize & 0xff); h[17] = (uint8_t)(bsize >> 8);
+        uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef*)pend_.data() + off, (uInt)len);
+        uint8_t* tl = h + 18 + clen;
+        for (int i = 0; i < 4; i++) tl[i] = (uint8_t)(crc >> (8 * i));
+        for (int i = 0; i < 4; i++) tl[4 + i] = (uint8_t)((uint32_t)len >> (8 * i));
+        o.resize(18 + clen + 8);
+      }
+    };
+    size_t nt = std::min<size_t>(4, nblk);
+    if (nt == 1) {
+      work(0, 1);
+    } else {
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < nt; t++) th.emplace_back(work, t, nt);
+      for (auto& x : th) x.join();
+    }
+    for (size_t b = 0; b < nblk; b++) {
+      if (bad[b]) return "bgzf: deflate failed";
+      if (fwrite(out[b].data(), 1, out[b].size(), f_) != out[b].size()) return "write " + path_ + ": short write";
+    }
+    pend_.erase(0, std::min(pend_.size(), nblk * kBlock));
+    return "";
+  }
+
+  bool bgzf_;
+  FILE* f_ = nullptr;
+  std::string path_, pend_;
+};
+
+// tsv.Writer restatement over a Sink.
+class Tsv {
+ public:
+  Tsv(bool bgzf) : sink_(bgzf) { buf_.reserve(kFlush + 4096); }
+  std::string Open(const std::string& path) { return sink_.Open(path); }
+  void WriteString(const char* s, size_t n) { buf_.append(s, n); buf_.push_back('\t'); }
+  void WriteString(const std::string& s) { WriteString(s.data(), s.size()); }
+  void WriteByte(char c) { buf_.push_back(c); buf_.push_back('\t'); }
+  void WriteUint32(uint32_t v) {
+    char t[12];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) buf_.push_back(t[--n]);
+    buf_.push_back('\t');
+  }
+  std::string EndLine() {
+    if (!buf_.empty() && buf_.back() == '\t') buf_.back() = '\n'; else buf_.push_back('\n');
+    if (buf_.size() >= kFlush) return Flush();
+    return "";
+  }
+  std::string Flush() {
+    std::string err = sink_.Write(buf_.data(), buf_.size());
+    buf_.clear();
+    return err;
+  }
+  std::string Close() {
+    std::string err = Flush();
+    std::string e2 = sink_.Close();
+    return err.empty() ? e2 : err;
+  }
+
+ private:
+  static constexpr size_t kFlush = 1 << 20;
+  Sink sink_;
+  std::string buf_;
+};
+
+struct RefLookup {
+  const std::vector<std::string>& names;
+  const std::vector<const std::string*>& seqs;
+  // Seq8 of (ref,pos); the reference indexes refSeqs[refID][pos] directly and would panic on a
+  // contig the .fa lacks (output.go:158), here that is an error.
+  std::string Get(int32_t ref, int32_t pos, uint8_t* out) const {
+    if (ref < 0 || (size_t)ref >= seqs.size() || !seqs[(size_t)ref] || (size_t)pos >= seqs[(size_t)ref]->size())
+      return "pileup output: no reference base for " +
+             (ref >= 0 && (size_t)ref < names.size() ? names[(size_t)ref] : std::string("?")) + ":" +
+             std::to_string((long long)pos + 1) + " (contig missing from .fa, or position past its end)";
+    *out = (uint8_t)(*seqs[(size_t)ref])[(size_t)pos];
+    return "";
+  }
+};
+
+class TsvWriter : public RowWriter {
+ public:
+  TsvWriter(int cols, bool bgz, const std::vector<std::string>& names, const std::vector<const std::string*>& seqs)
+      : cols_(cols), ref_(bgz), alt_(bgz), lk_{names, seqs} {}
+  std::string Open(const std::string& main_path, bool bgz) {
+    std::string err = ref_.Open(main_path + ".ref.tsv" + (bgz ? ".gz" : ""));
+    if (!err.empty()) return err;
+    err = alt_.Open(main_path + ".alt.tsv" + (bgz ? ".gz" : ""));
+    if (!err.empty()) return err;
+    ref_.WriteString("#CHROM\tPOS\tREF");
+    alt_.WriteString("#CHROM\tPOS\tREF\tALT");
+    if (cols_ & kColDpRef) ref_.WriteString("DP");
+    if (cols_ & kColDpAlt) alt_.WriteString("DP");
+    if (cols_ & kColHighQ) { ref_.WriteString("ref_depth_tier1"); alt_.WriteString("alt_depth_tier1"); }
+    if (cols_ & kColLowQ) { ref_.WriteString("ref_depth_tier2"); alt_.WriteString("alt_depth_tier2"); }
+    err = ref_.EndLine();
+    if (!err.empty()) return err;
+    return alt_.EndLine();
+  }
+  std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n) override {
+    std::string err;
+    for (int64_t i = 0; i < n; i++) {
+      const uint32_t* v = vals + i * BP_ROW_U32;
+      uint8_t b8;
+      err = lk_.Get(ref_id[i], pos[i], &b8);
+      if (!err.empty()) return err;
+      const std::string& name = lk_.names[(size_t)ref_id[i]];
+      const char ref_char = kSeq8ToASCII[b8 & 15];
+      const int ref_base = kSeq8ToEnum[b8 & 15];
+      ref_.WriteString(name);
+      ref_.WriteUint32((uint32_t)pos[i] + 1);
+      ref_.WriteByte(ref_char);
+      if (cols_ & kColDpRef) ref_.WriteUint32(v[0]);
+      if (cols_ & kColHighQ) ref_.WriteUint32(v[1 + 2 * ref_base] + v[2 + 2 * ref_base]);
+      if (cols_ & kColLowQ) ref_.WriteByte('0');
+      err = ref_.EndLine();
+      if (!err.empty()) return err;
+      for (int alt = 0; alt < 5; alt++) {
+        if (alt == ref_base) continue;
+        const uint32_t c = v[1 + 2 * alt] + v[2 + 2 * alt];
+        if (!c) continue;
+        alt_.WriteString(name);
+        alt_.WriteUint32((uint32_t)pos[i] + 1);
+        alt_.WriteByte(ref_char);
+        alt_.WriteByte(kEnumToASCII[alt]);
+        if (cols_ & kColDpAlt) alt_.WriteUint32(v[0]);
+        if (cols_ & kColHighQ) alt_.WriteUint32(c);
+        if (cols_ & kColLowQ) alt_.WriteByte('0');
+        err = alt_.EndLine();
+        if (!err.empty()) return err;
+      }
+    }
+    return "";
+  }
+  std::string Close() override {
+    std::string e1 = ref_.Close(), e2 = alt_.Close();
+    return e1.empty() ? e2 : e1;
+  }
+
+ private:
+  int cols_;
+  Tsv ref_, alt_;
+  RefLookup lk_;
+};
+
+class BasestrandTsvWriter : public RowWriter {
+ public:
+  BasestrandTsvWriter(bool bgz, const std::vector<std::string>& names, const std::vector<const std::string*>& seqs)
+      : w_(bgz), lk_{names, seqs} {}
+  std::string Open(const std::string& main_path, bool bgz) {
+    std::string err = w_.Open(main_path + ".basestrand.tsv" + (bgz ? ".gz" : ""));
+    if (!err.empty()) return err;
+    w_.WriteString("#CHROM\tPOS\tREF\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-");
+    return w_.EndLine();
+  }
+  std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n) override {
+    std::string err;
+    for (int64_t i = 0; i < n; i++) {
+      const uint32_t* v = vals + i * BP_ROW_U32;
+      uint8_t b8;
+      err = lk_.Get(ref_id[i], pos[i], &b8);
+      if (!err.empty()) return err;
+      w_.WriteString(lk_.names[(size_t)ref_id[i]]);
+      w_.WriteUint32((uint32_t)pos[i] + 1);
+      w_.WriteByte(kSeq8ToASCII[b8 & 15]);
+      for (int k = 0; k < 8; k++) w_.WriteUint32(v[1 + k]);
+      err = w_.EndLine();
+      if (!err.empty()) return err;
+    }
+    return "";
+  }
+  std::string Close() override { return w_.Close(); }
+
+ private:
+  Tsv w_;
+  RefLookup lk_;
+};
+
+}  // namespace
+
+std::unique_ptr<RowWriter> NewTsvWriter(const std::string& main_path, int col_bitset, bool bgzip,
+                                        const std::vector<std::string>& ref_names,
+                                        const std::vector<const std::string*>& ref_seqs, std::string* err) {
+  std::unique_ptr<TsvWriter> w(new TsvWriter(col_bitset, bgzip, ref_names, ref_seqs));
+  *err = w->Open(main_path, bgzip);
+  if (!err->empty()) return nullptr;
+  return std::unique_ptr<RowWriter>(w.release());
+}
+
+std::unique_ptr<RowWriter> NewBasestrandTsvWriter(const std::string& main_path, int col_bitset, bool bgzip,
+                                                  const std::vector<std::string>& ref_names,
+                                                  const std::vector<const std::string*>& ref_seqs,
+                                                  std::string* err) {
+  (void)col_bitset;  // per-read column sets are rejected before a writer is made
+  std::unique_ptr<BasestrandTsvWriter> w(new BasestrandTsvWriter(bgzip, ref_names, ref_seqs));
+  *err = w->Open(main_path, bgzip);
+  if (!err->empty()) return nullptr;
+  return std::unique_ptr<RowWriter>(w.release());
+}
+
+}  // namespace bio

@@ -1,0 +1,348 @@
+// pileup.cpp -- bio::Pileup, the host driver around the device hot path (reference:
+// snp.Pileup pileup/snp/pileup.go:970-1130 and pileupSNPMain :812-968).
+//
+// Job structure.  The reference cuts the genome into 100 kb shards, gives each of
+// `parallelism` goroutines a run of shards with a maxReadSpan halo and the BED Subset of
+// exactly its range (pileup.go:862-909), and concatenates the per-job rows.  Counts are sums
+// of commutative per-base updates, so any cut into position ranges with that halo gives the
+// same rows; here a job is a range of one contig of at most `kJobSpan` positions (one job per
+// human contig), sized for HBM rather than for CPU cores, and jobs run one after another on
+// the device while the next one's records are decoded.  `-region` keeps the reference's
+// single unpadded shard (pileup.go:1091-1096): reads that start before the region start are
+// never seen.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "bio_host.h"
+
+namespace bio {
+
+namespace {
+
+constexpr int64_t kSubmitRecords = 1 << 20;  // records per bp_submit
+constexpr int64_t kRowChunk = 1 << 20;       // rows per bp_rows copy
+
+int64_t JobSpan() {
+  // Positions per job.  BIO_PILEUP_JOB_SPAN exists for tests of the halo logic.
+  const char* e = getenv("BIO_PILEUP_JOB_SPAN");
+  if (e && *e) {
+    long long v = atoll(e);
+    if (v > 0) return v;
+  }
+  return 1ll << 28;
+}
+
+struct Job {
+  int ref;
+  PosType start, end;  // positions [start, end) of contig `ref`
+};
+
+struct Stream {  // one output stream = one strand pass (pileup.go:1118-1128)
+  int strand_req = BP_STRAND_NONE;
+  std::unique_ptr<RowWriter> writer;
+  bp_handle* h = nullptr;
+};
+
+std::string HandleErr(bp_handle* h) { return bp_last_error(h); }
+
+void AppendRecord(RecordBatchBuilder* b, const BamReader::Raw& r) {
+  b->ref_id.push_back(r.ref_id);
+  b->pos.push_back(r.pos);
+  b->mate_ref_id.push_back(r.mate_ref_id);
+  b->mate_pos.push_back(r.mate_pos);
+  b->flags.push_back(r.flags);
+  b->mapq.push_back(r.mapq);
+  b->n_cigar.push_back(r.n_cigar);
+  b->l_seq.push_back(r.l_seq);
+  b->cigar_off.push_back(b->cigar.size());
+  size_t o = b->cigar.size();
+  b->cigar.resize(o + r.n_cigar);
+  if (r.n_cigar) memcpy(b->cigar.data() + o, r.cigar, 4 * (size_t)r.n_cigar);
+  b->seq_off.push_back(b->seq.size());
+  b->seq.insert(b->seq.end(), r.seq, r.seq + ((size_t)r.l_seq + 1) / 2);
+  b->qual_off.push_back(b->qual.size());
+  b->qual.insert(b->qual.end(), r.qual, r.qual + r.l_seq);
+  if (b->keep_names) {
+    b->name_off.push_back(b->name.size());
+    b->name.insert(b->name.end(), (const uint8_t*)r.name, (const uint8_t*)r.name + r.l_name);
+  }
+}
+
+class Driver {
+ public:
+  Driver(const Opts& o, const BamHeader& hd, const BEDUnion& bed, int fmt_ignore_strand)
+      : opts_(o), hd_(hd), bed_(bed), ignore_strand_(fmt_ignore_strand) {}
+
+  std::vector<Stream> streams;
+
+  std::string OpenJob(const Job& j) {
+    BEDUnion part = bed_.Subset(j.ref, j.start, j.ref, j.end);
+    std::vector<const char*> names;
+    for (const auto& s : hd_.ref_names) names.push_back(s.c_str());
+    for (Stream& s : streams) {
+      bp_opts bo;
+      memset(&bo, 0, sizeof(bo));
+      bo.clip = opts_.Clip;
+      bo.flag_exclude = opts_.FlagExclude;
+      bo.mapq = opts_.Mapq;
+      bo.max_read_len = opts_.MaxReadLen;
+      bo.max_read_span = opts_.MaxReadSpan;
+      bo.min_base_qual = opts_.MinBaseQual;
+      bo.stitch = opts_.Stitch;
+      bo.ignore_strand = ignore_strand_;
+      bo.strand_req = s.strand_req;
+      bo.device = opts_.Device;
+      if (bp_create(&bo, (int32_t)hd_.ref_lens.size(), hd_.ref_lens.data(), names.data(), &s.h) != BP_OK)
+        return HandleErr(nullptr);
+      const std::vector<PosType>& e = part.id_map[(size_t)j.ref];
+      if (bp_set_bed(s.h, j.ref, e.data(), (int32_t)e.size()) != BP_OK) return HandleErr(s.h);
+    }
+    return "";
+  }
+
+  std::string Submit(RecordBatchBuilder* b) {
+    if (b->size() == 0) return "";
+    bp_record_batch v = b->view();
+    for (Stream& s : streams)
+      if (bp_submit(s.h, &v) != BP_OK) return HandleErr(s.h);
+    b->clear();
+    return "";
+  }
+
+  std::string CloseJob() {
+    std::vector<int32_t> ref(kRowChunk), pos(kRowChunk);
+    std::vector<uint32_t> vals((size_t)kRowChunk * BP_ROW_U32);
+    for (Stream& s : streams) {
+      if (bp_finish(s.h) != BP_OK) return HandleErr(s.h);
+      const int64_t n = bp_num_rows(s.h);
+      for (int64_t first = 0; first < n; first += kRowChunk) {
+        const int64_t m = std::min(kRowChunk, n - first);
+        if (bp_rows(s.h, first, m, ref.data(), pos.data(), vals.data()) != BP_OK) return HandleErr(s.h);
+        std::string err = s.writer->Write(ref.data(), pos.data(), vals.data(), m);
+        if (!err.empty()) return err;
+      }
+      bp_destroy(s.h);
+      s.h = nullptr;
+    }
+    return "";
+  }
+
+  void Abort() {
+    for (Stream& s : streams) {
+      if (s.h) bp_destroy(s.h);
+      s.h = nullptr;
+    }
+  }
+
+ private:
+  const Opts& opts_;
+  const BamHeader& hd_;
+  const BEDUnion& bed_;
+  int ignore_strand_;
+};
+
+}  // namespace
+
+std::string Pileup(const std::string& xampath, const std::string& fapath, const std::string& format,
+                   const std::string& out_prefix, const Opts& opts) {
+  // 1. options (pileup.go:974-1025)
+  if (opts.Clip < 0 || opts.Clip * 2 >= opts.MaxReadLen) return "Pileup: invalid clip= argument";
+  if (opts.MaxReadLen > opts.MaxReadSpan)
+    return "Pileup: max-read-len= argument cannot be larger than max-read-span= argument";
+  enum { kRio, kBsTsv, kBsTsvBgz, kTsv, kTsvBgz } fmt;
+  if (format == "basestrand-rio") fmt = kRio;
+  else if (format == "basestrand-tsv") fmt = kBsTsv;
+  else if (format == "basestrand-tsv-bgz") fmt = kBsTsvBgz;
+  else if (format == "tsv") fmt = kTsv;
+  else if (format == "tsv-bgz") fmt = kTsvBgz;
+  else return "Pileup: unrecognized format= argument";
+  const int cols_default = kColDpRef | kColHighQ | kColLowQ;
+  int cols = cols_default;
+  if (!opts.Cols.empty()) {
+    if (fmt == kRio) return "Pileup: -cols cannot be used with basestrand-rio output";
+    std::string err = ParseCols(opts.Cols, cols_default, &cols);
+    if (!err.empty()) return err;
+  }
+
+  // 2. BAM header, BED / region (pileup.go:1042-1105)
+  if (opts.Region.empty() && opts.BedPath.empty()) return "Pileup: either -bed or -region is currently required";
+  if (xampath.size() >= 4 && xampath.compare(xampath.size() - 4, 4, ".pam") == 0)
+    return "Pileup: PAM input is not supported by this build (BAM only)";
+  BamReader bam;
+  {
+    std::string err = bam.Open(xampath);
+    if (!err.empty()) return err;
+  }
+  const BamHeader& hd = bam.header();
+  BEDUnion bed;
+  Entry region;
+  if (!opts.Region.empty()) {
+    std::string err = ParseRegionString(opts.Region, &region);
+    if (!err.empty()) return err;
+  }
+  int region_ref = -1;
+  if (!opts.BedPath.empty()) {
+    if (!opts.Region.empty()) return "Pileup: -region and -bed flags can't be used together yet";
+    std::string err = BEDUnion::FromPath(opts.BedPath, hd.ref_names, &bed);
+    if (!err.empty()) return err;
+  } else {
+    for (size_t i = 0; i < hd.ref_names.size(); i++)
+      if (hd.ref_names[i] == region.ref_name) { region_ref = (int)i; break; }
+    if (region_ref < 0) return "Pileup: region= contig not in BAM/PAM";
+    // A contig-only region is [0, 2^31-2) in the reference (bedunion.go:599-603), which then
+    // walks off the end of the reference sequence at output time (output.go:158).  Clamp to
+    // the contig length instead (documented divergence).
+    if (region.end > hd.ref_lens[(size_t)region_ref]) region.end = hd.ref_lens[(size_t)region_ref];
+    if (region.start0 >= region.end) return "Pileup: region= starts past the end of contig " + region.ref_name;
+    std::string err = BEDUnion::FromEntries({region}, hd.ref_names, &bed);
+    if (!err.empty()) return err;
+  }
+
+  // 3. reference sequences (pileup.go:1107-1114)
+  Fasta fa;
+  {
+    std::string err = LoadFaSeq8(fapath, &fa);
+    if (!err.empty()) return err;
+  }
+  std::vector<const std::string*> ref_seqs;
+  std::string warnings;
+  {
+    std::string err = FaToStringSlice(fa, hd, &ref_seqs, &warnings);
+    if (!err.empty()) return err;
+    if (!warnings.empty()) fputs(warnings.c_str(), stderr);
+  }
+
+  // 4. pileupSNPMain set-up (pileup.go:812-835, :887-888, :944-966)
+  const bool tsv_format = fmt == kTsv || fmt == kTsvBgz;
+  if (opts.PerStrand && !tsv_format)
+    return "pileupSNPMain: single-strand mode not supported with basestrand output (strands are already "
+           "tracked separately)";
+  if (opts.MinBaseQual < 0 || opts.MinBaseQual >= 96) return "newQualPassTable: minBaseQual too large";
+  if (fmt == kRio)
+    return "Pileup: basestrand-rio output is not supported by this build (the recordio container lives in "
+           "grailbio/base, which the reference tree does not include); use basestrand-tsv";
+  if (cols & (kColEndDists | kColQuals | kColFraglens | kColStrands))
+    return "Pileup: per-read column sets (enddists, quals, fraglens, strands) are not supported by this build";
+  if (bp_init(opts.Device) != BP_OK) return bp_last_error(nullptr);
+
+  Driver drv(opts, hd, bed, tsv_format ? 1 : 0);
+  const int n_stream = opts.PerStrand ? 2 : 1;
+  drv.streams.resize((size_t)n_stream);
+  for (int s = 0; s < n_stream; s++) {
+    Stream& st = drv.streams[(size_t)s];
+    std::string main_path = out_prefix;
+    if (opts.PerStrand) {
+      st.strand_req = s == 0 ? BP_STRAND_FWD : BP_STRAND_REV;
+      main_path += s == 0 ? ".strand.fwd" : ".strand.rev";
+    }
+    std::string err;
+    const bool bgz = fmt == kTsvBgz || fmt == kBsTsvBgz;
+    st.writer = tsv_format ? NewTsvWriter(main_path, cols, bgz, hd.ref_names, ref_seqs, &err)
+                           : NewBasestrandTsvWriter(main_path, cols, bgz, hd.ref_names, ref_seqs, &err);
+    if (!err.empty()) return err;
+  }
+
+  // 5. jobs: BED-covered ranges of each contig, at most JobSpan() positions each
+  const int64_t job_span = std::max<int64_t>(JobSpan(), (int64_t)opts.MaxReadSpan + 1);
+  std::vector<Job> jobs;
+  for (size_t r = 0; r < bed.id_map.size(); r++) {
+    const std::vector<PosType>& e = bed.id_map[r];
+    if (e.size() < 2) continue;
+    for (int64_t s = (int64_t)e.front() / job_span * job_span; s < e.back(); s += job_span) {
+      const int64_t t = std::min<int64_t>(s + job_span, kPosTypeMax);
+      if (bed.IntersectsByID((int)r, (PosType)s, (PosType)t)) jobs.push_back({(int)r, (PosType)s, (PosType)t});
+    }
+  }
+
+  // 6. one pass over the BAM.  `cur` collects records of jobs[ji]; `halo` collects the ones
+  //    that start inside the next job's padding [next.start - maxReadSpan, next.start)
+  //    (gbam.Shard.PaddedStart, encoding/bam/shard.go:64-120).
+  const bool need_aux = opts.MinBagDepth != 0 || opts.RemoveSq;
+  RecordBatchBuilder cur, halo;
+  cur.keep_names = halo.keep_names = opts.Stitch;
+  size_t ji = 0;
+  bool open = false;
+  std::string err;
+  auto open_job = [&]() -> std::string {
+    std::string e = drv.OpenJob(jobs[ji]);
+    open = e.empty();
+    return e;
+  };
+  auto close_job = [&]() -> std::string {
+    std::string e = drv.Submit(&cur);
+    if (e.empty()) e = drv.CloseJob();
+    open = false;
+    ji++;
+    std::swap(cur, halo);
+    halo.clear();
+    return e;
+  };
+  BamReader::Raw r;
+  int32_t last_ref = -1, last_pos = -1;
+  while (ji < jobs.size()) {
+    int rc = bam.Next(&r);
+    if (rc < 0) { err = bam.err(); break; }
+    if (rc == 0) break;
+    if (r.ref_id < 0) break;  // unplaced reads sort last
+    if (r.ref_id < last_ref || (r.ref_id == last_ref && r.pos < last_pos)) {
+      err = "Pileup: BAM is not coordinate-sorted at " + std::string(r.name, r.l_name);
+      break;
+    }
+    last_ref = r.ref_id;
+    last_pos = r.pos;
+    if (region_ref >= 0) {  // iterator of the single region shard (bamprovider.go:417-435)
+      if (r.ref_id < region_ref || (r.ref_id == region_ref && r.pos < region.start0)) continue;
+      if (r.ref_id > region_ref || r.pos >= region.end) break;
+    }
+    // jobs that end at or before this record are complete
+    while (ji < jobs.size() && (jobs[ji].ref < r.ref_id || (jobs[ji].ref == r.ref_id && jobs[ji].end <= r.pos))) {
+      if (!open && !(err = open_job()).empty()) break;
+      if (!(err = close_job()).empty()) break;
+    }
+    if (!err.empty() || ji >= jobs.size()) break;
+    const Job& j = jobs[ji];
+    if (j.ref != r.ref_id) continue;  // contig without BED positions before the next job
+    if (need_aux) {
+      // Same read-level predicate the device applies first (pileup.go:691), so the aux tags
+      // are only demanded of reads the reference would have asked (pileup.go:695-716).
+      if ((opts.FlagExclude & r.flags) || opts.Mapq > (int)r.mapq || r.n_cigar == 0) continue;
+      int64_t v = 0;
+      if (opts.RemoveSq) {
+        if (!AuxInt(r.aux, r.l_aux, "DL", &v)) { err = "sam.Record.LibraryBagSize: no DL aux tag on read " + std::string(r.name, r.l_name); break; }
+        if (v < 2) continue;
+      }
+      if (opts.MinBagDepth != 0) {
+        if (!AuxInt(r.aux, r.l_aux, "DS", &v)) { err = "sam.Record.BagSize: no DS aux tag on read " + std::string(r.name, r.l_name); break; }
+        if (v < opts.MinBagDepth) continue;
+      }
+    }
+    // Reads ahead of the job's padded start cannot reach it but still go through the
+    // library's read checks, as they do in whichever reference job scans them.
+    if (!open && !(err = open_job()).empty()) break;
+    AppendRecord(&cur, r);
+    if (ji + 1 < jobs.size() && jobs[ji + 1].ref == r.ref_id &&
+        (int64_t)r.pos >= (int64_t)jobs[ji + 1].start - opts.MaxReadSpan)
+      AppendRecord(&halo, r);
+    if (cur.size() >= kSubmitRecords && !(err = drv.Submit(&cur)).empty()) break;
+  }
+  // jobs after the last record still emit their (zero) rows (flushEmptyContigs,
+  // pileup_support.go:112-123)
+  while (err.empty() && ji < jobs.size()) {
+    if (!open && !(err = open_job()).empty()) break;
+    err = close_job();
+  }
+  if (!err.empty()) {
+    drv.Abort();
+    return err;
+  }
+  for (Stream& s : drv.streams) {
+    std::string e = s.writer->Close();
+    if (!e.empty()) return e;
+  }
+  return "";
+}
+
+}  // namespace bio

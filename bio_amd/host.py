@@ -1,0 +1,119 @@
+"""Python face of the C++ host layers in libbiopileup.so (include/bio_pileup_host.h): the
+snp.Pileup driver (pileup/snp/pileup.go:970-1130), the bio-pileup command line
+(cmd/bio-pileup/main.go) and the parsers they are built from.  Everything here calls the
+native library; nothing is computed in Python."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .snp import Opts, PileupError
+
+# column-set bits (pileup.go:134-157)
+COL_DPREF, COL_DPALT, COL_ENDDISTS, COL_QUALS, COL_FRAGLENS, COL_STRANDS, COL_HIGHQ, COL_LOWQ = (
+    1, 2, 4, 8, 16, 32, 64, 128)
+COLS_DEFAULT = COL_DPREF | COL_HIGHQ | COL_LOWQ
+
+
+def _err():
+    return C.create_string_buffer(1024)
+
+
+def _b(s):
+    return None if s is None else s.encode()
+
+
+def pileup(xampath, fapath, fmt="tsv", out_prefix="bio-pileup", opts=None, device=0):
+    """snp.Pileup (pileup.go:970).  Raises PileupError with the reference's wording."""
+    o = opts or Opts()
+    lib = _abi.load()
+    co = _abi.bio_pileup_opts()
+    lib.bio_pileup_default_opts(C.byref(co))
+    co.bed_path, co.region, co.bam_index_path = _b(o.BedPath), _b(o.Region), _b(o.BamIndexPath)
+    co.clip, co.cols, co.flag_exclude, co.mapq = o.Clip, _b(o.Cols), o.FlagExclude, o.Mapq
+    co.max_read_len, co.max_read_span = o.MaxReadLen, o.MaxReadSpan
+    co.min_bag_depth, co.min_base_qual, co.parallelism = o.MinBagDepth, o.MinBaseQual, o.Parallelism
+    co.per_strand, co.remove_sq, co.stitch = int(o.PerStrand), int(o.RemoveSq), int(o.Stitch)
+    co.temp_dir, co.device = _b(o.TempDir), device
+    e = _err()
+    if lib.bio_pileup_run(_b(xampath), _b(fapath), _b(fmt), _b(out_prefix), C.byref(co), e, len(e)):
+        raise PileupError(-1, e.value.decode())
+
+
+def main(argv):
+    """cmd/bio-pileup main(); argv[0] is the program name.  Returns the exit status."""
+    lib = _abi.load()
+    arr = (C.c_char_p * (len(argv) + 1))(*[a.encode() for a in argv], None)
+    return lib.bio_pileup_main(len(argv), arr)
+
+
+def parse_region(region):
+    """interval.ParseRegionString -> (ref_name, start0, end)"""
+    lib = _abi.load()
+    name = C.create_string_buffer(4096)
+    s, t, e = C.c_int32(), C.c_int32(), _err()
+    if lib.bio_parse_region(region.encode(), name, len(name), C.byref(s), C.byref(t), e, len(e)):
+        raise ValueError(e.value.decode())
+    return name.value.decode(), s.value, t.value
+
+
+def parse_cols(cols, default=COLS_DEFAULT):
+    lib = _abi.load()
+    out, e = C.c_int32(), _err()
+    if lib.bio_parse_cols(cols.encode(), default, C.byref(out), e, len(e)):
+        raise ValueError(e.value.decode())
+    return out.value
+
+
+class Bed:
+    """interval.BEDUnion loaded from a path against a list of reference names."""
+
+    def __init__(self, path, ref_names, subset=None):
+        self._h = None
+        lib = _abi.load()
+        self._lib = lib
+        names = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+        sub = (C.c_int32 * 4)(*subset) if subset is not None else None
+        h, e = C.c_void_p(), _err()
+        if lib.bio_bed_load(path.encode(), len(ref_names), names, sub, C.byref(h), e, len(e)):
+            raise ValueError(e.value.decode())
+        self._h = h
+
+    def endpoints(self, ref_id):
+        """EndpointsByID; None for a reference the BED never mentions."""
+        n = self._lib.bio_bed_endpoints(self._h, ref_id, None, 0)
+        if n < 0:
+            return None
+        out = np.zeros(n, np.int32)
+        self._lib.bio_bed_endpoints(self._h, ref_id, out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out
+
+    def intersects(self, ref_id, start, limit):
+        return bool(self._lib.bio_bed_intersects(self._h, ref_id, start, limit))
+
+    def close(self):
+        if self._h:
+            self._lib.bio_bed_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def fasta_seq8(path, name):
+    lib = _abi.load()
+    e = _err()
+    n = lib.bio_fasta_seq8(path.encode(), name.encode(), None, 0, e, len(e))
+    if n < 0:
+        raise ValueError(e.value.decode())
+    out = np.zeros(n, np.uint8)
+    lib.bio_fasta_seq8(path.encode(), name.encode(), out.ctypes.data_as(C.POINTER(C.c_uint8)), n, e, len(e))
+    return out
+
+
+def bam_scan(path):
+    """-> (n_records, sum l_seq, sum n_cigar, n_ref) as the driver's BAM reader decodes them"""
+    lib = _abi.load()
+    a, b, c, d, e = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32(), _err()
+    if lib.bio_bam_scan(path.encode(), C.byref(a), C.byref(b), C.byref(c), C.byref(d), e, len(e)):
+        raise ValueError(e.value.decode())
+    return a.value, b.value, c.value, d.value

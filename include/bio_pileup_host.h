@@ -1,0 +1,83 @@
+/*
+ * bio_pileup_host.h -- C ABI of the host layers of libbiopileup.so that sit on either side of
+ * the device hot path (include/bio_pileup.h): the snp.Pileup driver, the bio-pileup command
+ * line, and the small parsers the driver is built from.  Plain C signatures; every function
+ * that can fail returns 0 on success or -1 with a message in `err` (NUL-terminated, cut to
+ * errlen).  Counts are only ever computed on the GPU: bio_pileup_run fails without one.
+ */
+#ifndef BIO_PILEUP_HOST_H_
+#define BIO_PILEUP_HOST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* snp.Opts (pileup/snp/pileup.go:36-54); defaults = snp.DefaultOpts (:56-68). Strings may be
+ * NULL (= ""). */
+typedef struct bio_pileup_opts {
+  const char* bed_path;
+  const char* region;
+  const char* bam_index_path;
+  int32_t clip;
+  const char* cols;
+  int32_t flag_exclude;
+  int32_t mapq;
+  int32_t max_read_len;
+  int32_t max_read_span;
+  int32_t min_bag_depth;
+  int32_t min_base_qual;
+  int32_t parallelism;
+  int32_t per_strand;
+  int32_t remove_sq;
+  int32_t stitch;
+  const char* temp_dir;
+  int32_t device; /* HIP device ordinal; no counterpart in the reference */
+} bio_pileup_opts;
+
+/* snp.DefaultOpts (pileup.go:56-68) */
+void bio_pileup_default_opts(bio_pileup_opts* o);
+
+/* snp.Pileup(ctx, xampath, fapath, format, outPrefix, opts, nil) (pileup.go:970-1130) */
+int bio_pileup_run(const char* xampath, const char* fapath, const char* format, const char* out_prefix,
+                   const bio_pileup_opts* opts, char* err, size_t errlen);
+
+/* cmd/bio-pileup main() (main.go:60-98); returns the process exit status */
+int bio_pileup_main(int argc, char** argv);
+
+/* interval.ParseRegionString (interval/bedunion.go:593-651) */
+int bio_parse_region(const char* region, char* ref_name, size_t ref_name_len, int32_t* start0, int32_t* end,
+                     char* err, size_t errlen);
+
+/* pileup.ParseCols with snp's column names (pileup/common.go:118-166, pileup.go:134-157) */
+int bio_parse_cols(const char* cols, int32_t default_bitset, int32_t* bitset, char* err, size_t errlen);
+
+/* interval.NewBEDUnionFromPath with a SAM header (bedunion.go:563-578, :343-364), then
+ * optionally Subset (bedunion.go:753-852) when subset[] = {startRef, startPos, limitRef,
+ * limitPos} is non-NULL.  Returns a handle; endpoints are read per reference ID. */
+typedef struct bio_bed bio_bed;
+int bio_bed_load(const char* path, int32_t n_ref, const char* const* ref_names, const int32_t* subset,
+                 bio_bed** out, char* err, size_t errlen);
+/* EndpointsByID (bedunion.go:326-328): returns the count; copies up to cap endpoints */
+int32_t bio_bed_endpoints(const bio_bed* b, int32_t ref_id, int32_t* endpoints, int32_t cap);
+/* IntersectsByID (bedunion.go:219-254) */
+int bio_bed_intersects(const bio_bed* b, int32_t ref_id, int32_t start, int32_t limit);
+void bio_bed_free(bio_bed* b);
+
+/* fasta.New(..., OptEncoding(Seq8)) + pileup.FaToStringSlice for one contig
+ * (encoding/fasta/fasta.go:132-175, pileup/common.go:194-225): copies up to cap Seq8 bytes
+ * of sequence `name`, returns its length or -1. */
+int64_t bio_fasta_seq8(const char* path, const char* name, uint8_t* seq8, int64_t cap, char* err,
+                       size_t errlen);
+
+/* BAM reader used by the driver (record layout per encoding/bam/unmarshal.go:126-224):
+ * counts records and sums l_seq and n_cigar over the file; for tests of the decoder. */
+int bio_bam_scan(const char* path, int64_t* n_records, int64_t* sum_l_seq, int64_t* sum_n_cigar,
+                 int32_t* n_ref, char* err, size_t errlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIO_PILEUP_HOST_H_ */

@@ -125,6 +125,16 @@ def region_shard(ref_id, start0, end):
     return arr, 1
 
 
+def bed_subset1(endpoints, start, limit):
+    """BEDUnion.Subset on one contig (bedunion.go:753-852) -> list of endpoints."""
+    lib = load()
+    ep = np.ascontiguousarray(endpoints, np.int32)
+    i32p = C.POINTER(C.c_int32)
+    out = np.zeros(len(ep) + 4, np.int32)
+    n = lib.orc_bed_subset1(ep.ctypes.data_as(i32p), len(ep), start, limit, out.ctypes.data_as(i32p), len(out))
+    return out[:n].tolist()
+
+
 class OracleError(RuntimeError):
     pass
 

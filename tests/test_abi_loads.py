@@ -18,6 +18,16 @@ def test_header_symbols_exported():
         assert hasattr(lib, name), name
 
 
+def test_host_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "bio_pileup_host.h")).read()
+    declared = set(re.findall(r"\b(bio_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_abi.HOST_EXPORTS), declared ^ set(_abi.HOST_EXPORTS)
+    lib = _abi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert C.sizeof(_abi.bio_pileup_opts) == 96
+
+
 def test_struct_sizes_match_header():
     # bp_opts: 16 int32; bp_record_batch: int64 + 16 pointers; bp_timing: 3 float + pad + 2 int64
     assert C.sizeof(_abi.bp_opts) == 64

@@ -1,0 +1,239 @@
+"""GPU end-to-end: BAM + FASTA + BED files -> bio::Pileup (C++ driver over the HIP path) ->
+TSV files, compared byte for byte with text rendered from the CPU oracle's rows by the
+rules of pileup/snp/output.go (restated below, test-side)."""
+import gzip
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from bio_amd import bamio, host, records as R
+from bio_amd.snp import Opts, PileupError
+from test_oracle_vs_naive import random_bed, random_records
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SEQ8_ASCII = "=ACMGRSVTWYHKDBN"          # pileup/common.go:72
+SEQ8_ENUM = [4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4]  # common.go:66
+ASCII_SEQ8 = {c: v for v, cs in ((1, "Aa"), (2, "Cc"), (4, "Gg"), (8, "Tt")) for c in cs}  # biosimd_amd64.go:471-487
+
+
+def render_tsv(rows, ref_names, ref_ascii, cols):
+    """output.go:83-131 header, :149-275 body -> (ref text, alt text)"""
+    ref, pos, vals = rows
+    hr, ha = ["#CHROM", "POS", "REF"], ["#CHROM", "POS", "REF", "ALT"]
+    if cols & host.COL_DPREF:
+        hr.append("DP")
+    if cols & host.COL_DPALT:
+        ha.append("DP")
+    if cols & host.COL_HIGHQ:
+        hr.append("ref_depth_tier1"); ha.append("alt_depth_tier1")
+    if cols & host.COL_LOWQ:
+        hr.append("ref_depth_tier2"); ha.append("alt_depth_tier2")
+    out_r, out_a = ["\t".join(hr)], ["\t".join(ha)]
+    for i in range(len(pos)):
+        name = ref_names[ref[i]]
+        b8 = ASCII_SEQ8.get(ref_ascii[ref[i]][pos[i]], 15)
+        ch, rb = SEQ8_ASCII[b8], SEQ8_ENUM[b8]
+        v = [int(x) for x in vals[i]]
+        cnt = [v[1 + 2 * b] + v[2 + 2 * b] for b in range(5)]
+        f = [name, str(pos[i] + 1), ch]
+        if cols & host.COL_DPREF:
+            f.append(str(v[0]))
+        if cols & host.COL_HIGHQ:
+            f.append(str(cnt[rb]))
+        if cols & host.COL_LOWQ:
+            f.append("0")
+        out_r.append("\t".join(f))
+        for alt in range(5):
+            if alt == rb or cnt[alt] == 0:
+                continue
+            f = [name, str(pos[i] + 1), ch, "ACGTN"[alt]]
+            if cols & host.COL_DPALT:
+                f.append(str(v[0]))
+            if cols & host.COL_HIGHQ:
+                f.append(str(cnt[alt]))
+            if cols & host.COL_LOWQ:
+                f.append("0")
+            out_a.append("\t".join(f))
+    return "\n".join(out_r) + "\n", "\n".join(out_a) + "\n"
+
+
+def render_basestrand(rows, ref_names, ref_ascii):
+    """output.go:400, :445-453"""
+    ref, pos, vals = rows
+    out = ["#CHROM\tPOS\tREF\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-"]
+    for i in range(len(pos)):
+        b8 = ASCII_SEQ8.get(ref_ascii[ref[i]][pos[i]], 15)
+        out.append("\t".join([ref_names[ref[i]], str(pos[i] + 1), SEQ8_ASCII[b8]] +
+                             [str(int(x)) for x in vals[i][1:9]]))
+    return "\n".join(out) + "\n"
+
+
+class Case:
+    def __init__(self, tmp_path, seed=11, n_pairs=2500, ref_lens=(9000, 4000, 6000, 3000), read_len=100,
+                 bed_refs=(0, 1, 3), aux=False):
+        rng = random.Random(seed)
+        self.tmp = tmp_path
+        self.ref_lens = list(ref_lens)
+        self.ref_names = [f"chr{k + 1}" for k in range(len(ref_lens))]
+        # reads on contigs 0, 2 and 3: contig 1 has BED positions but no reads (flushEmptyContigs)
+        recs = []
+        for r in (0, 2, 3):
+            part = random_records(rng, n_pairs // 3, ref_len=ref_lens[r], read_len=read_len)
+            for x in part:
+                x["name"] = f"c{r}{x['name']}"
+                x["mate_ref_id"] = r if x["mate_ref_id"] == x["ref_id"] else (r + 1) % len(ref_lens)
+                x["ref_id"] = r
+            recs += part
+        recs.sort(key=lambda x: (x["ref_id"], x["pos"]))
+        self.recs = recs
+        self.batch = R.from_records(recs)
+        self.ref_ascii = ["".join(rng.choice("ACGTacgtNR") if rng.random() < 0.1 else rng.choice("ACGT")
+                                  for _ in range(l)) for l in ref_lens]
+        full = {r: iv for r in bed_refs for iv in [random_bed(rng, ref_lens[r], dense=True)[0]]}
+        self.bed = full
+        self.bam = str(tmp_path / "in.bam")
+        self.aux = None
+        if aux:
+            # DS as type C, DL as type i; one read without tags is placed where filters drop it
+            self.ds = [rng.randint(0, 5) for _ in recs]
+            self.dl = [rng.randint(0, 3) for _ in recs]
+            self.aux = [b"XAZhello\0" + b"DSC" + bytes([a]) + b"DLi" + int(b).to_bytes(4, "little")
+                        for a, b in zip(self.ds, self.dl)]
+        bamio.write_bam(self.bam, self.ref_names, self.ref_lens, self.batch, aux=self.aux)
+        # contig 2 (index 2) is missing from the FASTA: tolerated, it has no BED positions
+        self.fa = str(tmp_path / "ref.fa")
+        keep = [k for k in range(len(ref_lens)) if k != 2 or 2 in bed_refs]
+        bamio.write_fasta(self.fa, [self.ref_names[k] for k in keep], [self.ref_ascii[k] for k in keep])
+        self.bed_path = str(tmp_path / "targets.bed")
+        bamio.write_bed(self.bed_path, [(r, s, e) for r in sorted(full) for s, e in full[r]], self.ref_names)
+
+    def oracle(self, **kw):
+        opts = O.make_opts(max_read_len=kw.pop("max_read_len", 500), max_read_span=kw.pop("max_read_span", 511), **kw)
+        return O.pileup(opts, self.ref_lens, self.bed, self.batch)
+
+    def read(self, name):
+        p = os.path.join(str(self.tmp), name)
+        if name.endswith(".gz"):
+            return gzip.open(p, "rb").read().decode()
+        return open(p).read()
+
+
+def test_bed_mode_tsv_and_basestrand(tmp_path):
+    c = Case(tmp_path)
+    out = str(tmp_path / "o")
+    host.pileup(c.bam, c.fa, "tsv", out, Opts(BedPath=c.bed_path, Mapq=30))
+    want = c.oracle(mapq=30, ignore_strand=1)
+    wr, wa = render_tsv(want, c.ref_names, c.ref_ascii, host.COLS_DEFAULT)
+    assert c.read("o.ref.tsv") == wr
+    assert c.read("o.alt.tsv") == wa
+    assert wa.count("\n") > 50 and int(want[2][:, 0].sum()) > 50000
+
+    host.pileup(c.bam, c.fa, "basestrand-tsv", out, Opts(BedPath=c.bed_path, Mapq=30, MinBaseQual=20))
+    want = c.oracle(mapq=30, min_base_qual=20, ignore_strand=0)
+    assert c.read("o.basestrand.tsv") == render_basestrand(want, c.ref_names, c.ref_ascii)
+
+
+def test_cols_and_bgz(tmp_path):
+    c = Case(tmp_path, seed=12)
+    out = str(tmp_path / "o")
+    host.pileup(c.bam, c.fa, "tsv-bgz", out, Opts(BedPath=c.bed_path, Cols="dpref,dpalt,highq", Clip=3))
+    want = c.oracle(clip=3, ignore_strand=1)
+    cols = host.COL_DPREF | host.COL_DPALT | host.COL_HIGHQ
+    wr, wa = render_tsv(want, c.ref_names, c.ref_ascii, cols)
+    assert c.read("o.ref.tsv.gz") == wr and c.read("o.alt.tsv.gz") == wa
+    # header of the reference's own expected file for -cols dpref,highq
+    # (cmd/bio-pileup/testdata/generic.ref.tsv.expected:1)
+    host.pileup(c.bam, c.fa, "tsv", out, Opts(BedPath=c.bed_path, Cols="dpref,highq"))
+    assert c.read("o.ref.tsv").split("\n")[0] == "#CHROM\tPOS\tREF\tDP\tref_depth_tier1"
+    assert c.read("o.alt.tsv").split("\n")[0] == "#CHROM\tPOS\tREF\tALT\talt_depth_tier1"
+    raw = open(out + ".ref.tsv.gz", "rb").read()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC" and raw.endswith(bamio._EOF)
+    host.pileup(c.bam, c.fa, "basestrand-tsv-bgz", out, Opts(BedPath=c.bed_path))
+    assert c.read("o.basestrand.tsv.gz") == render_basestrand(c.oracle(), c.ref_names, c.ref_ascii)
+
+
+@pytest.mark.parametrize("stitch", [False, True])
+def test_job_cuts_with_halo_change_nothing(tmp_path, stitch, monkeypatch):
+    """Cutting contigs into many small device jobs (halo = max-read-span, like the reference's
+    padded shards) gives the same files as one job per contig."""
+    c = Case(tmp_path, seed=13 + stitch)
+    o = Opts(BedPath=c.bed_path, Stitch=stitch, MinBaseQual=25, MaxReadLen=150, MaxReadSpan=300)
+    want = render_basestrand(c.oracle(stitch=int(stitch), min_base_qual=25, max_read_len=150, max_read_span=300),
+                             c.ref_names, c.ref_ascii)
+    host.pileup(c.bam, c.fa, "basestrand-tsv", str(tmp_path / "one"), o)
+    assert c.read("one.basestrand.tsv") == want
+    for span in (301, 700, 2500):
+        monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(span))
+        host.pileup(c.bam, c.fa, "basestrand-tsv", str(tmp_path / "cut"), o)
+        assert c.read("cut.basestrand.tsv") == want, span
+
+
+def test_per_strand(tmp_path):
+    c = Case(tmp_path, seed=15)
+    out = str(tmp_path / "ps")
+    host.pileup(c.bam, c.fa, "tsv", out, Opts(BedPath=c.bed_path, PerStrand=True, Stitch=True))
+    for sfx, req in ((".strand.fwd", 1), (".strand.rev", 2)):
+        want = c.oracle(stitch=1, ignore_strand=1, strand_req=req)
+        wr, wa = render_tsv(want, c.ref_names, c.ref_ascii, host.COLS_DEFAULT)
+        assert c.read("ps" + sfx + ".ref.tsv") == wr
+        assert c.read("ps" + sfx + ".alt.tsv") == wa
+
+
+def test_region_mode(tmp_path):
+    """-region: one unpadded shard (pileup.go:1091-1096) - reads starting before the region
+    are never seen; a contig-only region is clamped to the contig (documented divergence)."""
+    c = Case(tmp_path, seed=16, bed_refs=(0,))
+    out = str(tmp_path / "r")
+    host.pileup(c.bam, c.fa, "basestrand-tsv", out, Opts(Region="chr1:2001-3500", Mapq=0))
+    opts = O.make_opts(mapq=0)
+    shard, n = O.region_shard(0, 2000, 3500)
+    want = O.pileup(opts, c.ref_lens, {0: [[2000, 3500]]}, c.batch, shards=shard, n_shards=n)
+    assert c.read("r.basestrand.tsv") == render_basestrand(want, c.ref_names, c.ref_ascii)
+    padded = O.pileup(opts, c.ref_lens, {0: [[2000, 3500]]}, c.batch)
+    assert (padded[2] != want[2]).any()  # the quirk is visible on this input
+
+    host.pileup(c.bam, c.fa, "basestrand-tsv", out, Opts(Region="chr4"))
+    shard, n = O.region_shard(3, 0, c.ref_lens[3])
+    want = O.pileup(O.make_opts(), c.ref_lens, {3: [[0, c.ref_lens[3]]]}, c.batch, shards=shard, n_shards=n)
+    assert c.read("r.basestrand.tsv") == render_basestrand(want, c.ref_names, c.ref_ascii)
+    host.pileup(c.bam, c.fa, "basestrand-tsv", out, Opts(Region="chr2:77"))
+    assert c.read("r.basestrand.tsv").split("\n")[1].split("\t")[:2] == ["chr2", "77"]
+
+
+def test_bag_filters(tmp_path):
+    """-min-bag-depth / -remove-sq read DS / DL aux tags on the host (pileup.go:695-716).
+    The hts accessors are not in the reference tree: absent-tag behaviour is parity unpinned."""
+    c = Case(tmp_path, seed=17, aux=True)
+    out = str(tmp_path / "b")
+    host.pileup(c.bam, c.fa, "basestrand-tsv", out, Opts(BedPath=c.bed_path, MinBagDepth=3, RemoveSq=True))
+    keep = np.array([a >= 3 and b >= 2 for a, b in zip(c.ds, c.dl)])
+    idx = np.nonzero(keep)[0]
+    want = O.pileup(O.make_opts(), c.ref_lens, c.bed, R.from_records([c.recs[i] for i in idx]))
+    assert c.read("b.basestrand.tsv") == render_basestrand(want, c.ref_names, c.ref_ascii)
+    assert 0 < len(idx) < c.batch.n
+
+
+def test_data_errors_surface_with_reference_wording(tmp_path):
+    c = Case(tmp_path, seed=18)
+    with pytest.raises(PileupError, match=r"pileupMutable.processShard: maxReadLen is 30, but read \S+ at chr\d:\d+ has length \d+"):
+        host.pileup(c.bam, c.fa, "tsv", str(tmp_path / "e"), Opts(BedPath=c.bed_path, MaxReadLen=30, MaxReadSpan=511))
+    # reads are at most 100 long; some carry a D or N op that pushes the span past 100
+    with pytest.raises(PileupError, match=r"maxReadSpan is 100, but read \S+ at chr\d:\d+ has span 1\d\d"):
+        host.pileup(c.bam, c.fa, "tsv", str(tmp_path / "e"), Opts(BedPath=c.bed_path, MaxReadLen=100, MaxReadSpan=100, Mapq=0))
+
+
+def test_cli_binary(tmp_path):
+    c = Case(tmp_path, seed=19)
+    exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
+    r = subprocess.run([exe, "-bed", c.bed_path, "-format=basestrand-tsv", "-stitch", "-min-base-qual", "20",
+                        "--out", str(tmp_path / "cli"), c.bam, c.fa], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = c.oracle(stitch=1, min_base_qual=20)
+    assert c.read("cli.basestrand.tsv") == render_basestrand(want, c.ref_names, c.ref_ascii)

@@ -4,17 +4,20 @@
 // Job structure.  The reference cuts the genome into 100 kb shards, gives each of
 // `parallelism` goroutines a run of shards with a maxReadSpan halo and the BED Subset of
 // exactly its range (pileup.go:862-909), and concatenates the per-job rows.  Counts are sums
-// of commutative per-base updates, so any cut into position ranges with that halo gives the
-// same rows; here a job is a range of one contig of at most `kJobSpan` positions (one job per
-// human contig), sized for HBM rather than for CPU cores, and jobs run one after another on
-// the device while the next one's records are decoded.  `-region` keeps the reference's
-// single unpadded shard (pileup.go:1091-1096): reads that start before the region start are
-// never seen.
+// of commutative per-base updates, so a cut into position ranges with enough padding gives
+// the rows of the single-job run (reference -parallelism 1); here a job is a range of one
+// contig of at most JobSpan() positions (one job per human contig), sized for HBM rather than
+// for CPU cores, and jobs run one after another on the device.  In the reference a pair whose
+// two reads fall on either side of a job boundary is stitched in neither job, so its output
+// depends mildly on -parallelism when flags are malformed; the padding used here (see step 6)
+// removes that dependence.  `-region` keeps the reference's single unpadded shard
+// (pileup.go:1091-1096): reads that start before the region start are never seen.
 #include <unistd.h>
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 
 #include "bio_host.h"
 
@@ -78,8 +81,11 @@ class Driver {
 
   std::vector<Stream> streams;
 
+  void SetPadding(int64_t bed_pad) { bed_pad_ = bed_pad; }
+
   std::string OpenJob(const Job& j) {
-    BEDUnion part = bed_.Subset(j.ref, j.start, j.ref, j.end);
+    BEDUnion part = bed_.Subset(j.ref, (PosType)std::max<int64_t>(0, (int64_t)j.start - bed_pad_), j.ref,
+                                (PosType)std::min<int64_t>(kPosTypeMax, (int64_t)j.end + bed_pad_));
     std::vector<const char*> names;
     for (const auto& s : hd_.ref_names) names.push_back(s.c_str());
     for (Stream& s : streams) {
@@ -112,7 +118,7 @@ class Driver {
     return "";
   }
 
-  std::string CloseJob() {
+  std::string CloseJob(const Job& j) {
     std::vector<int32_t> ref(kRowChunk), pos(kRowChunk);
     std::vector<uint32_t> vals((size_t)kRowChunk * BP_ROW_U32);
     for (Stream& s : streams) {
@@ -121,7 +127,11 @@ class Driver {
       for (int64_t first = 0; first < n; first += kRowChunk) {
         const int64_t m = std::min(kRowChunk, n - first);
         if (bp_rows(s.h, first, m, ref.data(), pos.data(), vals.data()) != BP_OK) return HandleErr(s.h);
-        std::string err = s.writer->Write(ref.data(), pos.data(), vals.data(), m);
+        // rows of the padding belong to the neighbouring jobs
+        const int64_t lo = std::lower_bound(pos.begin(), pos.begin() + m, j.start) - pos.begin();
+        const int64_t hi = std::lower_bound(pos.begin(), pos.begin() + m, j.end) - pos.begin();
+        if (lo >= hi) continue;
+        std::string err = s.writer->Write(ref.data() + lo, pos.data() + lo, vals.data() + lo * BP_ROW_U32, hi - lo);
         if (!err.empty()) return err;
       }
       bp_destroy(s.h);
@@ -142,6 +152,7 @@ class Driver {
   const BamHeader& hd_;
   const BEDUnion& bed_;
   int ignore_strand_;
+  int64_t bed_pad_ = 0;
 };
 
 }  // namespace
@@ -257,12 +268,21 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     }
   }
 
-  // 6. one pass over the BAM.  `cur` collects records of jobs[ji]; `halo` collects the ones
-  //    that start inside the next job's padding [next.start - maxReadSpan, next.start)
-  //    (gbam.Shard.PaddedStart, encoding/bam/shard.go:64-120).
+  // 6. one pass over the BAM.  Job k is fed the records that start in
+  //    [start_k - pad, end_k + pad_end) and computes the BED positions of that padded range;
+  //    only its rows in [start_k, end_k) are written.  Without stitching pad = maxReadSpan
+  //    on the left (gbam.Shard.PaddedStart, encoding/bam/shard.go:64-120) is all a position
+  //    can see.  With stitching a read's mate, and the BED positions that decide whether the
+  //    mate is kept (pileup.go:773-777), lie up to two spans away on either side; padding by
+  //    that much makes every job see its pairs exactly as one whole-contig job would, so the
+  //    output does not depend on where the cuts fall.  pend[k - ji] holds what job k has
+  //    been given so far; only the front job has device handles open.
   const bool need_aux = opts.MinBagDepth != 0 || opts.RemoveSq;
-  RecordBatchBuilder cur, halo;
-  cur.keep_names = halo.keep_names = opts.Stitch;
+  const int64_t pad = opts.Stitch ? 2 * (int64_t)opts.MaxReadSpan : (int64_t)opts.MaxReadSpan;
+  const int64_t pad_end = opts.Stitch ? pad : 0;
+  drv.SetPadding(opts.Stitch ? pad : 0);
+  std::deque<RecordBatchBuilder> pend(1);
+  pend[0].keep_names = true;  // stitching keys on names; error messages quote them
   size_t ji = 0;
   bool open = false;
   std::string err;
@@ -272,12 +292,15 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     return e;
   };
   auto close_job = [&]() -> std::string {
-    std::string e = drv.Submit(&cur);
-    if (e.empty()) e = drv.CloseJob();
+    std::string e = drv.Submit(&pend[0]);
+    if (e.empty()) e = drv.CloseJob(jobs[ji]);
     open = false;
     ji++;
-    std::swap(cur, halo);
-    halo.clear();
+    pend.pop_front();
+    if (pend.empty()) {
+      pend.emplace_back();
+      pend[0].keep_names = true;  // stitching keys on names; error messages quote them
+    }
     return e;
   };
   BamReader::Raw r;
@@ -297,14 +320,14 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
       if (r.ref_id < region_ref || (r.ref_id == region_ref && r.pos < region.start0)) continue;
       if (r.ref_id > region_ref || r.pos >= region.end) break;
     }
-    // jobs that end at or before this record are complete
-    while (ji < jobs.size() && (jobs[ji].ref < r.ref_id || (jobs[ji].ref == r.ref_id && jobs[ji].end <= r.pos))) {
+    // jobs whose padded range ends at or before this record are complete
+    while (ji < jobs.size() &&
+           (jobs[ji].ref < r.ref_id || (jobs[ji].ref == r.ref_id && (int64_t)jobs[ji].end + pad_end <= r.pos))) {
       if (!open && !(err = open_job()).empty()) break;
       if (!(err = close_job()).empty()) break;
     }
     if (!err.empty() || ji >= jobs.size()) break;
-    const Job& j = jobs[ji];
-    if (j.ref != r.ref_id) continue;  // contig without BED positions before the next job
+    if (jobs[ji].ref != r.ref_id) continue;  // contig without BED positions
     if (need_aux) {
       // Same read-level predicate the device applies first (pileup.go:691), so the aux tags
       // are only demanded of reads the reference would have asked (pileup.go:695-716).
@@ -319,14 +342,19 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
         if (v < opts.MinBagDepth) continue;
       }
     }
-    // Reads ahead of the job's padded start cannot reach it but still go through the
-    // library's read checks, as they do in whichever reference job scans them.
+    // The front job also takes reads ahead of its padded start: they cannot reach it, but
+    // they go through the library's read checks as they do in whichever reference job
+    // scans them.
     if (!open && !(err = open_job()).empty()) break;
-    AppendRecord(&cur, r);
-    if (ji + 1 < jobs.size() && jobs[ji + 1].ref == r.ref_id &&
-        (int64_t)r.pos >= (int64_t)jobs[ji + 1].start - opts.MaxReadSpan)
-      AppendRecord(&halo, r);
-    if (cur.size() >= kSubmitRecords && !(err = drv.Submit(&cur)).empty()) break;
+    AppendRecord(&pend[0], r);
+    for (size_t k = ji + 1; k < jobs.size() && jobs[k].ref == r.ref_id && (int64_t)jobs[k].start - pad <= r.pos; k++) {
+      if (pend.size() <= k - ji) {
+        pend.emplace_back();
+        pend.back().keep_names = true;  // stitching keys on names; error messages quote them
+      }
+      AppendRecord(&pend[k - ji], r);
+    }
+    if (pend[0].size() >= kSubmitRecords && !(err = drv.Submit(&pend[0])).empty()) break;
   }
   // jobs after the last record still emit their (zero) rows (flushEmptyContigs,
   // pileup_support.go:112-123)

@@ -2,7 +2,7 @@
 //
 //   plan_windows_kernel   per window: the range of coordinate-sorted records that can
 //                         overlap it (binary search on (ref_id,pos)).
-//   pileup_kernel         one workgroup per window: read filters (pileup.go:691, :717-729),
+//   pileup_kernel         per window: read filters (pileup.go:691, :717-729),
 //                         inline 4-bit unpack (replaces biosimd.UnpackSeq, firstread.go:64),
 //                         CIGAR walk (pileup.go:275-363), clip (pileup_support.go:51-69),
 //                         count rule (pileup.go:223-231), mate-overlap rule (pileup.go:406-446)
@@ -10,17 +10,24 @@
 //                         Depth + Counts[5][2] per BED position (pileup.go:518-570).
 //   column_sums_kernel    checksum of the rows.
 //
-// Mapping (wave64): a wave takes 64 records at a time; lane l reads record l's 32-byte core
-// and applies the read-level filters.  The kept records are then expanded into "units" of 8
-// consecutive read bases (one 8-byte qual load + one 4-byte packed-seq load per lane), laid
-// out so consecutive lanes hold consecutive units of the same record.  The LDS histogram is
-// counter-major (cnt[code][position]) with the position index permuted as
-// (p & 7) * W/8 + (p >> 3): lanes of one record that handle the same base-in-unit k hit
-// consecutive banks, so a record never conflicts with itself whatever the depth.
+// Mapping (wave64, 512-thread workgroups).  A workgroup owns kWinPerBlock consecutive
+// windows of kW reference positions and walks them one after the other:
+//   phase 1  thread = record.  Read-level filters, then the CIGAR walk turns every M op into
+//            a segment clipped to the window; a wave hands out segment and unit slots with
+//            one shuffle prefix sum and ONE packed 64-bit LDS atomic.
+//   phase 2  thread = unit = the 8 window positions [8j, 8j+8) of one segment: one unaligned
+//            12-byte qual load + one 8-byte packed-base load, realigned in registers, then 8
+//            ds_add_u32 whose addresses differ only by an immediate.  kDepth units are in
+//            flight per lane in a branch-free software pipeline.
+//   flush    thread = position: Depth = sum of the 12 planes, row written with 3 wide
+//            stores, planes zeroed on the way out.
+// The LDS histogram is counter-major (cnt[plane][position]) with position p = 8j + k stored
+// at k*kSub + j (kSub = kW/8 + 4): consecutive lanes hold consecutive units j of the same
+// segment, so the 8 adds of a wave instruction hit consecutive banks whatever the depth.
 //
 // Depth is not accumulated separately: every aligned base adds exactly one counter, either
-// its Counts[base][strand] slot or slot 10 ("depth only": base failed the quality rule), and
-// Depth = sum of the 11 counters at flush.  One LDS atomic per aligned base.
+// its Counts[base][strand] slot or a "depth only" slot (planes 10/11: base failed the quality
+// rule), and Depth = sum of the 12 planes at flush.  One LDS atomic per aligned base.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

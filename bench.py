@@ -114,12 +114,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-        tb = torch.tensor([B], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        total_B = int(tb.item())
+        # the only communication of a multi-GPU run: MAX of elapsed, SUM of bases
+        from bio_amd import partition
+        elapsed, total_B = partition.reduce_timing(dist, elapsed, B, device="cuda")
     else:
         total_B = B
 

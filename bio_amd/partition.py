@@ -1,0 +1,106 @@
+"""Genomic partitioning for multi-GPU runs: rank g owns a contiguous coordinate range and
+receives the records of its padded range -- the reference's own job structure
+(pileupSNPMain, pileup/snp/pileup.go:862-909: shard slice per job, BED Subset of exactly
+its range, maxReadSpan padding), with no data-path collective.  Host logic only; the counts
+of a partition come from the device path (bio_amd.snp)."""
+import numpy as np
+
+
+def bed_positions(bed):
+    return sum(e - s for iv in bed.values() for s, e in iv)
+
+
+def plan_partitions(bed, world_size):
+    """Cut the BED positions (ascending (ref,pos) order) into world_size contiguous runs of
+    near-equal size.  Returns, per rank, a list of (ref_id, start, end) ranges (a run may
+    span contigs).  Never splits a position; ranks can be empty when there are fewer
+    positions than ranks."""
+    total = bed_positions(bed)
+    cuts = [(total * g) // world_size for g in range(world_size + 1)]
+    parts = [[] for _ in range(world_size)]
+    g, done = 0, 0
+    for ref in sorted(bed):
+        for s, e in bed[ref]:
+            while s < e:
+                while g < world_size - 1 and done >= cuts[g + 1]:
+                    g += 1
+                take = e - s if g == world_size - 1 else min(e - s, cuts[g + 1] - done)
+                if take <= 0:
+                    g += 1
+                    continue
+                if parts[g] and parts[g][-1][0] == ref and parts[g][-1][2] == s:
+                    parts[g][-1] = (ref, parts[g][-1][1], s + take)
+                else:
+                    parts[g].append((ref, s, s + take))
+                s += take
+                done += take
+    return parts
+
+
+def subset_bed(bed, ranges, pad=0):
+    """BED restricted to the (padded) ranges: {ref: [[s,e],...]}, sorted and disjoint."""
+    out = {}
+    for ref, s, e in ranges:
+        lo, hi = max(0, s - pad), e + pad
+        for a, b in bed.get(ref, []):
+            x, y = max(a, lo), min(b, hi)
+            if x < y:
+                iv = out.setdefault(ref, [])
+                if iv and iv[-1][1] >= x:
+                    iv[-1][1] = max(iv[-1][1], y)
+                else:
+                    iv.append([x, y])
+    return out
+
+
+def padding(max_read_span, stitch):
+    """(records left, records right, BED) padding of a partition.  Unstitched, a position
+    only sees reads that start up to maxReadSpan before it (gbam.Shard.PaddedStart).
+    Stitched, a read's mate and the BED positions that decide whether the mate is kept lie
+    up to two spans away on either side (see bio_amd/csrc/host/pileup.cpp step 6)."""
+    if stitch:
+        return 2 * max_read_span, 2 * max_read_span, 2 * max_read_span
+    return max_read_span, 0, 0
+
+
+def record_spans(batch, ranges, pad_left, pad_right):
+    """Index spans [(lo,hi),...] (ascending, disjoint) of the coordinate-sorted records that
+    start inside any padded range; feed them to RecordBatch.take_spans / slice."""
+    key = batch.ref_id.astype(np.int64) << 32 | batch.pos.astype(np.int64)
+    spans = []
+    for ref, s, e in ranges:
+        lo = int(np.searchsorted(key, (ref << 32) | max(0, s - pad_left), "left"))
+        hi = int(np.searchsorted(key, (ref << 32) | (e + pad_right), "left"))
+        if spans and lo <= spans[-1][1]:
+            spans[-1][1] = max(spans[-1][1], hi)
+        elif hi > lo:
+            spans.append([lo, hi])
+    return [(a, b) for a, b in spans]
+
+
+def run_partition(bopts, ref_len, bed, batch, ranges, max_read_span, stitch, ref_names=None):
+    """Rows of one partition from the device path: padded records and BED in, own rows out."""
+    from . import snp
+    pl, pr, pb = padding(max_read_span, stitch)
+    part = batch.take_spans(record_spans(batch, ranges, pl, pr))
+    rows = snp.run_job(bopts, ref_len, subset_bed(bed, ranges, pb), [part], ref_names)
+    return own_rows(rows, ranges)
+
+
+def own_rows(rows, ranges):
+    """Drop the rows of the padding: keep (ref,pos) inside the rank's own ranges."""
+    ref, pos, vals = rows
+    keep = np.zeros(len(pos), bool)
+    for r, s, e in ranges:
+        keep |= (ref == r) & (pos >= s) & (pos < e)
+    return ref[keep], pos[keep], vals[keep]
+
+
+def reduce_timing(dist, elapsed_s, units, device="cpu"):
+    """bench.py's only communication: MAX of the ranks' elapsed time, SUM of their units."""
+    import torch
+    te = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    tu = torch.tensor([units], dtype=torch.int64, device=device)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tu, op=dist.ReduceOp.SUM)
+    return float(te.item()), int(tu.item())

@@ -91,6 +91,28 @@ class RecordBatch:
         kw["name_off"] = None if self.name_off is None else self.name_off[lo:hi + 1]
         return RecordBatch(**kw)
 
+    def take_spans(self, spans):
+        """Records of the index spans [(lo,hi),...] (ascending, disjoint) as one batch; payload
+        arrays are shared, names are re-gathered so name_off stays n+1 contiguous entries."""
+        spans = [(int(a), int(b)) for a, b in spans if b > a]
+        kw = {k: getattr(self, k) for k in ("cigar", "seq", "qual")}
+        for k in ("ref_id", "pos", "mate_ref_id", "mate_pos", "flags", "mapq", "n_cigar", "l_seq",
+                  "cigar_off", "seq_off", "qual_off"):
+            a = getattr(self, k)
+            kw[k] = np.concatenate([a[lo:hi] for lo, hi in spans]) if spans else a[:0]
+        kw["name_off"], kw["name"] = None, None
+        if self.name_off is not None:
+            offs, blobs, run = [], [], 0
+            for lo, hi in spans:
+                b0, b1 = int(self.name_off[lo]), int(self.name_off[hi])
+                offs.append(self.name_off[lo:hi].astype(np.int64) - b0 + run)
+                blobs.append(self.name[b0:b1])
+                run += b1 - b0
+            offs.append(np.array([run], np.int64))
+            kw["name_off"] = np.concatenate(offs).astype(np.uint64)
+            kw["name"] = np.concatenate(blobs) if blobs else np.zeros(0, np.uint8)
+        return RecordBatch(**kw)
+
     def aligned_bases(self):
         """Sum of CIGAR-M lengths (the unit of BASELINE.json's metric, before filters)."""
         ops = self.cigar & 15

@@ -232,3 +232,31 @@ def test_checksum_properties_at_scale():
         s2 = job.column_sums()
         assert s2[0] == sums[0]
         assert [s2[1 + 2 * b] + s2[2 + 2 * b] for b in range(5)] == [sums[1 + 2 * b] for b in range(5)]
+
+
+@pytest.mark.parametrize("stitch", [0, 1])
+def test_logical_partitions_on_one_device(stitch):
+    """G genomic partitions (what G ranks would own) computed one after
+    the other on this device must concatenate to the one-job rows bit for bit."""
+    from bio_amd import partition as P
+    rng = random.Random(77 + stitch)
+    ref_lens = [6000, 3000]
+    recs = []
+    for r, L in enumerate(ref_lens):
+        part = random_records(rng, 500, ref_len=L, read_len=60)
+        for x in part:
+            x["name"] = f"c{r}{x['name']}"
+            x["mate_ref_id"] = r if x["mate_ref_id"] == x["ref_id"] else 1 - r
+            x["ref_id"] = r
+        recs += part
+    recs.sort(key=lambda x: (x["ref_id"], x["pos"]))
+    batch = R.from_records(recs)
+    bed = {r: random_bed(rng, L, dense=True)[0] for r, L in enumerate(ref_lens)}
+    opts = O.make_opts(max_read_len=100, max_read_span=150, stitch=stitch, min_base_qual=20)
+    want = device_rows(opts, ref_lens, bed, [batch])
+    assert_same(want, O.pileup(opts, ref_lens, bed, batch), "one job")
+    for world in (2, 3, 7):
+        parts = [P.run_partition(opts, ref_lens, bed, batch, rg, 150, bool(stitch))
+                 for rg in P.plan_partitions(bed, world)]
+        got = tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+        assert_same(got, want, f"{world} partitions stitch={stitch}")

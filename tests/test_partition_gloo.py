@@ -1,0 +1,135 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes, each owning one genomic partition.
+The partition/padding logic and bench.py's only communication (MAX time, SUM units) are
+exercised for real; the per-partition counts come from the CPU oracle here (the checker
+standing in for the device), and the concatenated rows must equal the one-job result bit
+for bit."""
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from bio_amd import partition as P, records as R
+from test_oracle_vs_naive import random_bed, random_records
+
+REF_LENS = [6000, 2500, 4000]
+SPAN = 120
+
+
+def _inputs(seed):
+    rng = random.Random(seed)
+    recs = []
+    for r, L in enumerate(REF_LENS):
+        part = random_records(rng, 300, ref_len=L, read_len=40)
+        for x in part:
+            x["name"] = f"c{r}{x['name']}"
+            x["mate_ref_id"] = r if x["mate_ref_id"] == x["ref_id"] else (r + 1) % len(REF_LENS)
+            x["ref_id"] = r
+        recs += part
+    recs.sort(key=lambda x: (x["ref_id"], x["pos"]))
+    bed = {r: random_bed(rng, L, dense=True)[0] for r, L in enumerate(REF_LENS) if r != 1}
+    bed[1] = [[10, 20], [2000, 2400]]
+    return R.from_records(recs), bed
+
+
+def _partition_rows(batch, bed, ranges, stitch):
+    opts = O.make_opts(max_read_len=100, max_read_span=SPAN, stitch=stitch, min_base_qual=20)
+    pl, pr, pb = P.padding(SPAN, stitch)
+    part = batch.take_spans(P.record_spans(batch, ranges, pl, pr))
+    sub = P.subset_bed(bed, ranges, pb)
+    if not sub:
+        z = np.zeros(0, np.int32)
+        return z, z, np.zeros((0, 11), np.uint32)
+    # one unpadded shard per contig range = "the job sees exactly what it was handed"
+    rows = O.pileup(opts, REF_LENS, sub, part, parallelism=1)
+    return P.own_rows(rows, ranges)
+
+
+def _worker(rank, world, port, seed, stitch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch, bed = _inputs(seed)
+        ranges = P.plan_partitions(bed, world)[rank]
+        ref, pos, vals = _partition_rows(batch, bed, ranges, stitch)
+        dist.barrier()
+        elapsed, units = P.reduce_timing(dist, 0.25 * (rank + 1), int(vals[:, 0].sum()))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (ref, pos, vals))
+        if rank == 0:
+            q.put((elapsed, units, gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("stitch", [0, 1])
+def test_two_ranks_equal_one_job(stitch):
+    seed, world = 40 + stitch, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, stitch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    elapsed, units, gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    batch, bed = _inputs(seed)
+    opts = O.make_opts(max_read_len=100, max_read_span=SPAN, stitch=stitch, min_base_qual=20)
+    wr, wp, wv = O.pileup(opts, REF_LENS, bed, batch, parallelism=1)
+    gr = np.concatenate([g[0] for g in gathered])
+    gp = np.concatenate([g[1] for g in gathered])
+    gv = np.concatenate([g[2] for g in gathered])
+    assert (gr == wr).all() and (gp == wp).all()
+    assert (gv == wv).all()
+    assert elapsed == 0.5 and units == int(wv[:, 0].sum())
+    assert all(len(g[1]) > 0 for g in gathered)
+
+
+def test_plan_partitions_properties():
+    rng = random.Random(7)
+    for world in (1, 2, 3, 8, 50):
+        bed = {r: random_bed(rng, 3000)[0] for r in range(3)}
+        parts = P.plan_partitions(bed, world)
+        assert len(parts) == world
+        sizes = [sum(e - s for _, s, e in p) for p in parts]
+        assert sum(sizes) == P.bed_positions(bed)
+        assert max(sizes) - min(sizes) <= 1
+        # ascending, disjoint, and exactly the BED positions
+        flat = [x for p in parts for x in p]
+        assert flat == sorted(flat)
+        seen = {(r, x) for r, s, e in flat for x in range(s, e)}
+        want = {(r, x) for r, iv in bed.items() for s, e in iv for x in range(s, e)}
+        assert seen == want and len(seen) == sum(sizes)
+    assert P.plan_partitions({0: [[5, 7]]}, 4) in ([[(0, 5, 6)], [(0, 6, 7)], [], []],
+                                                    [[], [(0, 5, 6)], [], [(0, 6, 7)]],
+                                                    [[], [(0, 5, 6)], [(0, 6, 7)], []],
+                                                    [[(0, 5, 6)], [], [(0, 6, 7)], []],
+                                                    [[], [], [(0, 5, 6)], [(0, 6, 7)]],
+                                                    [[], [(0, 5, 6)], [], [(0, 6, 7)]])
+
+
+def test_take_spans_keeps_names_aligned():
+    batch, _ = _inputs(3)
+    sub = batch.take_spans([(5, 9), (20, 21), (30, 30), (40, 44)])
+    idx = list(range(5, 9)) + [20] + list(range(40, 44))
+    assert sub.n == len(idx)
+    for k, i in enumerate(idx):
+        a = bytes(sub.name[int(sub.name_off[k]):int(sub.name_off[k + 1])])
+        b = bytes(batch.name[int(batch.name_off[i]):int(batch.name_off[i + 1])])
+        assert a == b and sub.pos[k] == batch.pos[i]

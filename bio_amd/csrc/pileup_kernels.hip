@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pileup_device.h"
 
 namespace bp {
@@ -58,7 +60,7 @@ namespace bp {
 #define BP_SEGCAP 512
 #endif
 #ifndef BP_UNITCAP
-#define BP_UNITCAP 8192
+#define BP_UNITCAP 6144
 #endif
 #ifndef BP_DEPTH
 #define BP_DEPTH 4
@@ -125,15 +127,29 @@ constexpr int kWinPerBlock = BP_WINS; // consecutive windows per workgroup
 //    lanes hold consecutive j of the same segment -> consecutive banks, and kStride % 32 == 0
 //    keeps that true across planes: a record never conflicts with itself at any depth.
 //  * flush: 32 consecutive positions of one plane sit at banks 4k + j: all distinct.
-struct __align__(16) BlockShared {
-  uint32_t cnt[kPlanes * kStride];
-  // segment list of the current round (structure of arrays)
+// Per-segment fields only the stitched and clipped paths read back.
+struct SegExtra {
   int32_t s_ref[kSegCap];       // segment start relative to the window start (may be < 0)
   uint32_t s_lenq0[kSegCap];    // length | read offset << 16
-  uint32_t s_blob[kSegCap];     // record payload offset (8-byte units)
   uint32_t s_lseqnc[kSegCap];   // l_seq | n_cigar << 16
-  uint32_t s_misc[kSegCap];     // first unit slot | strand slot << 15 | first window unit << 16
-  int32_t s_rec[kSegCap];       // record index (stitch)
+  int32_t s_rec[kSegCap];       // record index
+};
+struct NoExtra {};
+
+// One M-segment of the current round, with everything a unit needs precomputed by the lane
+// that walked the CIGAR:
+//   x  low 32 bits of the byte address of the packed bases of the segment's first unit
+//      (4-byte aligned); unit u reads 8 bytes at x + 4u
+//   y  0..2 address bits 32..34 | 3..5 nibble shift | 6 strand slot | 8..15 valid-base mask
+//      of the first unit | 16..23 of the last unit | 24..31 number of units - 1
+//   z  0..14 first unit slot | 16..23 first window unit | 24..25 qual byte shift
+//   w  (qual address of the first unit, 4-byte aligned) - (base address above); unit u reads
+//      12 bytes at x + w + 8u
+template <bool EXTRA>
+struct __align__(16) BlockSharedT {
+  uint32_t cnt[kPlanes * kStride];
+  uint4 seg[kSegCap];
+  typename std::conditional<EXTRA, SegExtra, NoExtra>::type ex;
   uint16_t owner[kUnitCap];     // unit slot -> segment
   unsigned long long n_alloc;   // segments << 32 | units handed out this round
   uint32_t pad_[2];
@@ -172,15 +188,27 @@ typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
 
+// Inclusive prefix sum over the wave with DPP row shifts and row broadcasts (6 VALU steps, no
+// LDS traffic).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
+
 // Admit one M-segment per lane into the round's list; called by every lane of the wave
 // (want = this lane has a segment).  Slots are handed out with a wave prefix sum and ONE
-// LDS atomic per wave on a packed (segments << 16 | units) counter, so unit slots grow with
+// LDS atomic per wave on a packed (segments << 32 | units) counter, so unit slots grow with
 // the segment index.  Returns false for a lane whose segment did not fit this round: the
 // caller keeps its cursor and retries next round.
-__device__ __forceinline__ bool emit_wave(BlockShared& S, bool want, int32_t sref, int32_t len,
+template <bool EXTRA>
+__device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool want, int32_t sref, int32_t len,
                                           int32_t q0, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
                                           uint32_t sslot, int32_t rec) {
-  const int lane = threadIdx.x & 63;
   const int32_t s1 = sref > 0 ? sref : 0;
   const int32_t e1 = (int64_t)sref + len < (int64_t)wlen ? sref + len : (int32_t)wlen;
   const bool real = want && e1 > s1;  // clipped-away segments need no slot
@@ -188,29 +216,42 @@ __device__ __forceinline__ bool emit_wave(BlockShared& S, bool want, int32_t sre
   const uint32_t U = real ? (((uint32_t)(e1 - 1) >> 3) - jlo + 1) : 0u;
   // inclusive prefix sums of (1, U) over the wave, packed as count << 16 | units
   // (a wave adds at most 64 segments x 129 units: no carry between the fields)
-  uint32_t incl = real ? (0x10000u | U) : 0u;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-    if (lane >= o) incl += v;
-  }
-  const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+  const uint32_t mine = real ? (0x10000u | U) : 0u;
+  const uint32_t incl = wave_inclusive_scan(mine);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   unsigned long long base = 0;
-  if (lane == 0 && total != 0)
+  if ((threadIdx.x & 63) == 0 && total != 0)
     base = atomicAdd(&S.n_alloc, ((unsigned long long)(total >> 16) << 32) | (total & 0xffffu));
-  const uint32_t base_u = (uint32_t)__shfl((int)(uint32_t)base, 0);
-  const uint32_t base_s = (uint32_t)__shfl((int)(uint32_t)(base >> 32), 0);
-  const uint32_t excl = incl - (real ? (0x10000u | U) : 0u);
+  const uint32_t base_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+  const uint32_t base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+  const uint32_t excl = incl - mine;
   const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
   const bool ok = idx < (uint32_t)kSegCap && us < (uint32_t)kUnitCap && us + U <= (uint32_t)kUnitCap;
   if (real) {
     if (ok) {
-      S.s_ref[idx] = sref;
-      S.s_lenq0[idx] = (uint32_t)len | ((uint32_t)q0 << 16);
-      S.s_blob[idx] = blob;
-      S.s_lseqnc[idx] = lseqnc;
-      S.s_misc[idx] = us | (sslot << 15) | (jlo << 16);
-      S.s_rec[idx] = rec;
+      // byte offsets inside the record payload [cigar padded to even][qual 8*Ur][seq 4*Ur]
+      const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
+      const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
+      const int32_t d = q0 - sref;                       // read index of window position 0
+      const int32_t b_first = d + (int32_t)(jlo * 8);    // read index of the first unit's base 0
+      const int32_t qo = cigb + b_first;
+      const int32_t so = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b_first >> 1);
+      const uint64_t sa = (uint64_t)blob * 8 + (uint64_t)(uint32_t)(so & ~3);
+      const uint32_t noff = 2u * ((uint32_t)so & 3u) + ((uint32_t)d & 1u);
+      const uint32_t fm = (0xffu << (s1 & 7)) & 0xffu;
+      const uint32_t lm = 0xffu >> (7 - ((e1 - 1) & 7));
+      uint4 r;
+      r.x = (uint32_t)sa;
+      r.y = (uint32_t)(sa >> 32) | (noff << 3) | (sslot << 6) | (fm << 8) | (lm << 16) | ((U - 1) << 24);
+      r.z = us | (jlo << 16) | (((uint32_t)qo & 3u) << 24);
+      r.w = (uint32_t)((qo & ~3) - (so & ~3));
+      S.seg[idx] = r;
+      if constexpr (EXTRA) {
+        S.ex.s_ref[idx] = sref;
+        S.ex.s_lenq0[idx] = (uint32_t)len | ((uint32_t)q0 << 16);
+        S.ex.s_lseqnc[idx] = lseqnc;
+        S.ex.s_rec[idx] = rec;
+      }
       for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
     } else {
       for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
@@ -224,6 +265,11 @@ struct UnitLoad {
   u32x2a sd;      // 8 bytes covering the unit's 8 packed bases
   uint32_t seg;   // segment | active << 16
   uint32_t jj;    // window unit (positions 8*jj .. 8*jj+7)
+  // Everything the plain (unstitched) path needs, packed at issue time so that processing
+  // does not touch the segment list again:
+  //   0..7 jj | 8..15 valid-base mask | 16..17 qual byte shift | 18..20 nibble shift |
+  //   21 strand slot
+  uint32_t meta;
 };
 
 // Byte offsets, inside a record's payload, of the unit's first qual / first packed base.
@@ -235,38 +281,110 @@ __device__ __forceinline__ void unit_offsets(uint32_t lseqnc, int32_t b0, int32_
 }
 
 // Loads are issued unconditionally (inactive lanes read the start of the payload buffer) so
-// that every issue is exactly two VMEM instructions and the counted vmcnt waits stay exact.
-__device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockShared& S, uint32_t t,
+// that every issue is the same number of VMEM instructions and the counted vmcnt waits stay
+// exact.  NEED_Q = false (min_base_qual 0, no stitching: every base passes the quality rule,
+// pileup.go:227) skips the qual load altogether.
+template <bool NEED_Q, bool EXTRA>
+__device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<EXTRA>& S, uint32_t t,
                                            uint32_t T, UnitLoad& L) {
   bool in = t < T;
   uint32_t s = S.owner[in ? t : 0];
   if (s == 0xffffu) { in = false; s = 0; }
-  const int32_t sref = S.s_ref[s];
-  const uint32_t lenq0 = S.s_lenq0[s];
-  const uint32_t lseqnc = S.s_lseqnc[s];
-  const uint32_t misc = S.s_misc[s];
-  const uint32_t bl = S.s_blob[s];
-  L.jj = in ? (misc >> 16) + (t - (misc & 0x7fffu)) : 0u;
+  const uint4 r = S.seg[s];
+  const uint32_t u = t - (r.z & 0x7fffu);
+  const uint32_t jj = ((r.z >> 16) & 0xffu) + u;
+  uint32_t mask = (u == 0 ? (r.y >> 8) : 0xffu) & (u == (r.y >> 24) ? (r.y >> 16) : 0xffu) & 0xffu;
+  mask = in ? mask : 0u;
+  L.jj = in ? jj : 0u;
   L.seg = s | (in ? 0x10000u : 0u);
-  const int32_t b0 = (int32_t)(lenq0 >> 16) + ((int32_t)(L.jj * 8) - sref);
-  int32_t qoff, soff;
-  unit_offsets(lseqnc, b0, qoff, soff);
-  uint64_t rec_off = (uint64_t)bl * 8;
-  if (!in) { qoff = 0; soff = 0; rec_off = 0; }
-  const uint8_t* bp_ = P.blob + rec_off;
-  L.qd = *(const u32x3a*)(bp_ + (qoff & ~3));
-  L.sd = *(const u32x2a*)(bp_ + (soff & ~3));
+  L.meta = L.jj | (mask << 8) | (((r.z >> 24) & 3u) << 16) | (((r.y >> 3) & 7u) << 18) | (((r.y >> 6) & 1u) << 21);
+  uint64_t off = (((uint64_t)(r.y & 7u) << 32) | r.x) + 4u * u;
+  if (!in) off = 0;
+  const uint8_t* sp = P.blob + off;
+  if constexpr (NEED_Q) {
+    const int64_t qd = in ? (int64_t)(int32_t)r.w + 4 * (int64_t)u : 0;
+    L.qd = *(const u32x3a*)(sp + qd);
+  }
+  L.sd = *(const u32x2a*)sp;
+}
+
+// The plain path: no stitching.  The 8 plane codes of a unit are computed together on the
+// nibble-packed bases (SWAR), so the per-base cost is two extractions, one multiply-add and
+// the LDS atomic.
+//   code c: A 0, C 1, G 2, T 3, X 4, depth-only 5  ->  plane 2c + strand slot
+// Seq8ToEnumTable (pileup/common.go:66): a nibble with exactly one bit set is a base
+// (log2 = its code); every other value is X.  A base failing the quality rule goes to the
+// depth-only planes, X is counted regardless (addBase, pileup.go:223-231).
+template <bool CLIP, bool MINQ0>
+__device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockSharedT<CLIP>& B,
+                                                   const UnitLoad& L) {
+  constexpr uint32_t M1 = 0x11111111u;
+  const uint32_t meta = L.meta;
+  // BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i
+  // (this is the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
+  const uint32_t x0 = ((L.sd.x & 0x0f0f0f0fu) << 4) | ((L.sd.x >> 4) & 0x0f0f0f0fu);
+  const uint32_t x1 = ((L.sd.y & 0x0f0f0f0fu) << 4) | ((L.sd.y >> 4) & 0x0f0f0f0fu);
+  const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, (meta >> 16) & 0x1cu);  // 4 * noff
+  const uint32_t t1 = sw >> 1, t2 = sw >> 2, t3 = sw >> 3;
+  const uint32_t lb0 = (t1 | t3) & M1, lb1 = (t2 | t3) & M1;       // log2 of a one-hot nibble
+  const uint32_t x = sw ^ t1, a = sw & t1;                          // pair parity / pair full
+  const uint32_t oh = (x ^ (x >> 2)) & ~(a | (a >> 2)) & M1;        // exactly one bit set
+  const uint32_t oh3 = oh | (oh << 1);
+  uint32_t cw = ((lb0 | (lb1 << 1)) & oh3) | ((oh ^ M1) << 2);      // one-hot ? log2 : 4 (X)
+  if constexpr (!MINQ0) {
+    // quality rule on the 8 quals at once: byte flag 0x80 = qual >= min_base_qual
+    const uint32_t qsh = (meta >> 16) & 3u;
+    const uint32_t qlo = __builtin_amdgcn_alignbyte(L.qd.y, L.qd.x, qsh);
+    const uint32_t qhi = __builtin_amdgcn_alignbyte(L.qd.z, L.qd.y, qsh);
+    constexpr uint32_t H = 0x80808080u;
+    const uint32_t minq4 = (uint32_t)P.min_base_qual * 0x01010101u;
+    uint32_t mlo = (((qlo | H) - minq4) | qlo) & H;
+    uint32_t mhi = (((qhi | H) - minq4) | qhi) & H;
+    // byte flags (bits 7,15,23,31) -> nibble-spaced flags (bits 7,11,15,19)
+    mlo = (mlo | (mlo >> 4)) & 0x08800880u;
+    mlo = (mlo | (mlo >> 8)) & 0x00088880u;
+    mhi = (mhi | (mhi >> 4)) & 0x08800880u;
+    mhi = (mhi | (mhi >> 8)) & 0x00088880u;
+    uint32_t pn = (mlo >> 7) | (mhi << 9);  // bit 4k = base k passes
+    if constexpr (CLIP) {
+      // clipQuals (pileup_support.go:51-69): the first and last `clip` bases of the read have
+      // quality 2
+      const uint32_t sg = L.seg & 0xffffu;
+      const int32_t b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + ((int32_t)((meta & 0xffu) * 8) - B.ex.s_ref[sg]);
+      const int32_t lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
+      const int32_t clip = P.clip;
+      int32_t nlo = clip - b0;                 // bases k < nlo are clipped
+      int32_t nhi = lseq - clip - b0;          // bases k >= nhi are clipped
+      if (2 * clip >= lseq) nlo = 8;
+      nlo = nlo < 0 ? 0 : (nlo > 8 ? 8 : nlo);
+      nhi = nhi < 0 ? 0 : (nhi > 8 ? 8 : nhi);
+      const uint32_t lo_m = nlo >= 8 ? M1 : (M1 & ((1u << (4 * nlo)) - 1u));
+      const uint32_t hi_m = nhi >= 8 ? 0u : (M1 & ~((1u << (4 * nhi)) - 1u));
+      const uint32_t cm = lo_m | hi_m;
+      pn = (uint32_t)P.min_base_qual <= 2u ? (pn | cm) : (pn & ~cm);
+    }
+    const uint32_t pn15 = (pn << 4) - pn;   // 0xf per passing base
+    const uint32_t cf = 0x44444444u | oh;          // failing: base -> depth-only (5), X stays X (4)
+    cw = (cw & pn15) | (cf & ~pn15);
+  }
+  const uint32_t cbase = ((meta & 0xffu) + ((meta >> 21) & 1u) * (uint32_t)kStride) * 4u;
+  char* const lds = (char*)B.cnt;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t c = (cw >> (4 * k)) & 7u;
+    const uint32_t val = (meta >> (8 + k)) & 1u;
+    atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + cbase + k * kSub * 4), val);
+  }
 }
 
 template <bool STITCH, bool CLIP>
-__device__ __forceinline__ void process_unit(const KernelParams& P, BlockShared& B,
+__device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT<true>& B,
                                              const UnitLoad& L, uint32_t wlen, int32_t g0) {
   const bool in = (L.seg & 0x10000u) != 0;
   const uint32_t s = L.seg & 0xffffu;
-  const int32_t sref = B.s_ref[s];
-  const uint32_t lenq0 = B.s_lenq0[s];
-  const uint32_t lseqnc = B.s_lseqnc[s];
-  const uint32_t misc = B.s_misc[s];
+  const int32_t sref = B.ex.s_ref[s];
+  const uint32_t lenq0 = B.ex.s_lenq0[s];
+  const uint32_t lseqnc = B.ex.s_lseqnc[s];
   const int32_t Pw = (int32_t)(L.jj * 8);
   const int32_t len = (int32_t)(lenq0 & 0xffffu);
   const uint32_t lseq = lseqnc & 0xffffu;
@@ -294,7 +412,7 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockShared&
   const uint32_t x1 = ((L.sd.y & 0x0f0f0f0fu) << 4) | ((L.sd.y >> 4) & 0x0f0f0f0fu);
   const uint32_t noff = 2u * ((uint32_t)soff & 3u) + ((uint32_t)b0 & 1u);
   const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, 4u * noff);
-  uint32_t sslot_u = (misc >> 15) & 1u;
+  uint32_t sslot_u = (L.meta >> 21) & 1u;
   const uint32_t minq = (uint32_t)P.min_base_qual;
   const int32_t clip = P.clip;
 
@@ -304,7 +422,7 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockShared&
   int32_t myrec = 0;
   if constexpr (STITCH) {
     if (in) {
-      myrec = B.s_rec[s];
+      myrec = B.ex.s_rec[s];
       const int32_t m = P.mate[myrec];
       if (m >= 0) {
         mate_idx = m >> 1;
@@ -370,15 +488,24 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockShared&
   }
 }
 
+template <bool STITCH, bool CLIP, bool MINQ0>
+__device__ __forceinline__ void unit(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
+                                     const UnitLoad& L, uint32_t wlen, int32_t g0) {
+  if constexpr (STITCH) process_unit<true, CLIP>(P, B, L, wlen, g0);
+  else process_unit_plain<CLIP, MINQ0>(P, B, L);
+}
+
 // Workgroup = kWinPerBlock consecutive windows, processed one after the other:
 //   phase 1  thread = record: read filters, CIGAR -> M-segments clipped to the window
 //   phase 2  thread = unit:   counts into the LDS planes
 //   flush    thread = position: Depth + Counts row to HBM, planes zeroed on the way out
 // The record cores of window i+1 are loaded while window i is in phase 2, so the only
 // exposed memory latency per window is that of the unit loads.
-template <bool STITCH, bool CLIP>
+template <bool STITCH, bool CLIP, bool MINQ0>
 __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParams P) {
-  __shared__ BlockShared S;
+  constexpr bool NEED_Q = STITCH || !MINQ0;
+  constexpr bool EXTRA = STITCH || CLIP;
+  __shared__ BlockSharedT<EXTRA> S;
   const int tid = threadIdx.x;
 
   // XCD-aware order: workgroups b and b+8 share an XCD (and its L2); give each XCD a
@@ -557,7 +684,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t0 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          issue_unit(P, S, tb + (tid & 63), T, L1);
+          issue_unit<NEED_Q>(P, S, tb + (tid & 63), T, L1);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -566,7 +693,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t2 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          process_unit<STITCH, CLIP>(P, S, L1, wlen, g0);
+          unit<STITCH, CLIP, MINQ0>(P, S, L1, wlen, g0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -587,22 +714,22 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         uint32_t t = (uint32_t)tid;
 #pragma unroll
         for (int d = 0; d < kDepth; d++) {
-          issue_unit(P, S, t, T, L[d]);
+          issue_unit<NEED_Q>(P, S, t, T, L[d]);
           t += kBlock;
         }
         uint32_t it = 0;
         for (; it + kDepth <= n_it; it += kDepth) {
 #pragma unroll
           for (int d = 0; d < kDepth; d++) {
-            process_unit<STITCH, CLIP>(P, S, L[d], wlen, g0);
-            issue_unit(P, S, t, T, L[d]);
+            unit<STITCH, CLIP, MINQ0>(P, S, L[d], wlen, g0);
+            issue_unit<NEED_Q>(P, S, t, T, L[d]);
             t += kBlock;
           }
         }
         const uint32_t rem = n_it - it;
 #pragma unroll
         for (int d = 0; d < kDepth - 1; d++)
-          if ((uint32_t)d < rem) process_unit<STITCH, CLIP>(P, S, L[d], wlen, g0);
+          if ((uint32_t)d < rem) unit<STITCH, CLIP, MINQ0>(P, S, L[d], wlen, g0);
       }
 #endif
       BP_STAMP(4);
@@ -692,11 +819,14 @@ void launch_pileup(const KernelParams& P, hipStream_t s) {
   const dim3 g((P.n_windows + kWinPerBlock - 1) / kWinPerBlock), b(kBlock);
   const bool clip = P.clip > 0;
   if (P.stitch) {
-    if (clip) hipLaunchKernelGGL((pileup_kernel<true, true>), g, b, 0, s, P);
-    else hipLaunchKernelGGL((pileup_kernel<true, false>), g, b, 0, s, P);
+    if (clip) hipLaunchKernelGGL((pileup_kernel<true, true, false>), g, b, 0, s, P);
+    else hipLaunchKernelGGL((pileup_kernel<true, false, false>), g, b, 0, s, P);
+  } else if (P.min_base_qual == 0) {
+    // every base passes the quality rule, clipped or not: the quals are never read
+    hipLaunchKernelGGL((pileup_kernel<false, false, true>), g, b, 0, s, P);
   } else {
-    if (clip) hipLaunchKernelGGL((pileup_kernel<false, true>), g, b, 0, s, P);
-    else hipLaunchKernelGGL((pileup_kernel<false, false>), g, b, 0, s, P);
+    if (clip) hipLaunchKernelGGL((pileup_kernel<false, true, false>), g, b, 0, s, P);
+    else hipLaunchKernelGGL((pileup_kernel<false, false, false>), g, b, 0, s, P);
   }
 }
 

@@ -85,7 +85,7 @@ struct bp_handle {
 
   // record bookkeeping
   int64_t n_reads = 0;
-  uint64_t blob_used = 0;  // in 8-byte units
+  uint64_t blob_used = 8;  // in 8-byte units; starts after a 64-byte pad (the first unit of a record may read a little before it)
   int64_t algo_in_bytes = 0;
   uint64_t last_key = 0;
   int32_t max_span = 1;

@@ -60,10 +60,13 @@ namespace bp {
 #define BP_SEGCAP 512
 #endif
 #ifndef BP_UNITCAP
-#define BP_UNITCAP 6144
+#define BP_UNITCAP 2048
 #endif
 #ifndef BP_DEPTH
-#define BP_DEPTH 4
+#define BP_DEPTH 3
+#endif
+#ifndef BP_DEPTHQ
+#define BP_DEPTHQ 2
 #endif
 #ifndef BP_WINS
 #define BP_WINS 8
@@ -113,20 +116,25 @@ __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* wi
   win_r1[w] = (int32_t)a;
 }
 
-constexpr int kSub = kW / 8 + 4;     // padded sub-row: 8 residues x kSub
-constexpr int kStride = 8 * kSub;    // dwords per counter plane (multiple of 32)
+constexpr int kUnitPos = 32;               // window positions per unit
+constexpr int kSub = kW / kUnitPos + 1;    // padded sub-row: 32 residues x kSub
+constexpr int kStride = kUnitPos * kSub;   // dwords per counter plane (multiple of 32)
 constexpr int kSegCap = BP_SEGCAP;   // M-segments per round
-constexpr int kUnitCap = BP_UNITCAP; // units (8 window positions of one segment) per round
+constexpr int kUnitCap = BP_UNITCAP; // units (32 window positions of one segment) per round
 constexpr int kDepth = BP_DEPTH;     // units in flight per lane (software pipeline depth)
+constexpr int kDepthQ = BP_DEPTHQ;   // ... when the quals are loaded too
 constexpr int kWinPerBlock = BP_WINS; // consecutive windows per workgroup
 
 // LDS histogram: 12 counter planes (A+ A- C+ C- G+ G- T+ T- X+ X- lowq+ lowq-), each plane
-// laid out by residue: position p = 8j + k lives at k*kSub + j.
-//  * accumulate: a lane handles the 8 positions of unit j of one M-segment, so its 8
-//    ds_add_u32 differ only in the instruction's immediate offset (k*kSub*4); consecutive
+// laid out by residue: position p = 32j + r lives at r*kSub + j.
+//  * accumulate: a lane handles the 32 positions of unit j of one M-segment, so its 32
+//    ds_add_u32 differ only in the instruction's immediate offset (r*kSub*4); consecutive
 //    lanes hold consecutive j of the same segment -> consecutive banks, and kStride % 32 == 0
 //    keeps that true across planes: a record never conflicts with itself at any depth.
-//  * flush: 32 consecutive positions of one plane sit at banks 4k + j: all distinct.
+//    Reads that overlap on the genome would hit the same counters in the same instruction;
+//    the unit slots are handed to lanes in an order that keeps the 8 groups of 8 lanes of a
+//    wave an eighth of the window apart (see issue_unit).
+//  * flush: 32 consecutive positions of one plane sit at banks r + j: all distinct.
 // Per-segment fields only the stitched and clipped paths read back.
 struct SegExtra {
   int32_t s_ref[kSegCap];       // segment start relative to the window start (may be < 0)
@@ -138,13 +146,15 @@ struct NoExtra {};
 
 // One M-segment of the current round, with everything a unit needs precomputed by the lane
 // that walked the CIGAR:
+// (a unit = the kUnitPos = 32 window positions [32j, 32j+32) of one segment)
 //   x  low 32 bits of the byte address of the packed bases of the segment's first unit
-//      (4-byte aligned); unit u reads 8 bytes at x + 4u
-//   y  0..2 address bits 32..34 | 3..5 nibble shift | 6 strand slot | 8..15 valid-base mask
-//      of the first unit | 16..23 of the last unit | 24..31 number of units - 1
-//   z  0..14 first unit slot | 16..23 first window unit | 24..25 qual byte shift
+//      (4-byte aligned); unit u reads 20 bytes at x + 16u
+//   y  0..2 address bits 32..34 | 3..5 nibble shift | 6 strand slot | 8..12 first valid
+//      position of the first unit | 13..17 last valid position of the last unit |
+//      24..29 number of units - 1
+//   z  0..14 first unit slot | 16..21 first window unit | 24..25 qual byte shift
 //   w  (qual address of the first unit, 4-byte aligned) - (base address above); unit u reads
-//      12 bytes at x + w + 8u
+//      36 bytes at x + w + 32u
 template <bool EXTRA>
 struct __align__(16) BlockSharedT {
   uint32_t cnt[kPlanes * kStride];
@@ -212,10 +222,10 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool want, int
   const int32_t s1 = sref > 0 ? sref : 0;
   const int32_t e1 = (int64_t)sref + len < (int64_t)wlen ? sref + len : (int32_t)wlen;
   const bool real = want && e1 > s1;  // clipped-away segments need no slot
-  const uint32_t jlo = (uint32_t)s1 >> 3;
-  const uint32_t U = real ? (((uint32_t)(e1 - 1) >> 3) - jlo + 1) : 0u;
+  const uint32_t jlo = (uint32_t)s1 >> 5;
+  const uint32_t U = real ? (((uint32_t)(e1 - 1) >> 5) - jlo + 1) : 0u;
   // inclusive prefix sums of (1, U) over the wave, packed as count << 16 | units
-  // (a wave adds at most 64 segments x 129 units: no carry between the fields)
+  // (a wave adds at most 64 segments x kW/32 units: no carry between the fields)
   const uint32_t mine = real ? (0x10000u | U) : 0u;
   const uint32_t incl = wave_inclusive_scan(mine);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -233,16 +243,15 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool want, int
       const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
       const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
       const int32_t d = q0 - sref;                       // read index of window position 0
-      const int32_t b_first = d + (int32_t)(jlo * 8);    // read index of the first unit's base 0
-      const int32_t qo = cigb + b_first;
+      const int32_t b_first = d + (int32_t)(jlo * 32);   // read index of the first unit's base 0
+      const int32_t qo = cigb + b_first;                 // >= -24: the payload buffer starts with a pad
       const int32_t so = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b_first >> 1);
       const uint64_t sa = (uint64_t)blob * 8 + (uint64_t)(uint32_t)(so & ~3);
       const uint32_t noff = 2u * ((uint32_t)so & 3u) + ((uint32_t)d & 1u);
-      const uint32_t fm = (0xffu << (s1 & 7)) & 0xffu;
-      const uint32_t lm = 0xffu >> (7 - ((e1 - 1) & 7));
       uint4 r;
       r.x = (uint32_t)sa;
-      r.y = (uint32_t)(sa >> 32) | (noff << 3) | (sslot << 6) | (fm << 8) | (lm << 16) | ((U - 1) << 24);
+      r.y = (uint32_t)(sa >> 32) | (noff << 3) | (sslot << 6) | (((uint32_t)s1 & 31u) << 8) |
+            (((uint32_t)(e1 - 1) & 31u) << 13) | ((U - 1) << 24);
       r.z = us | (jlo << 16) | (((uint32_t)qo & 3u) << 24);
       r.w = (uint32_t)((qo & ~3) - (so & ~3));
       S.seg[idx] = r;
@@ -260,16 +269,16 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool want, int
   return ok || !real;
 }
 
+// One unit in flight: the loaded bytes and everything processing needs, so that the plain
+// path does not touch the segment list again.
+template <bool NEED_Q>
 struct UnitLoad {
-  u32x3a qd;      // 12 bytes covering the unit's 8 quals
-  u32x2a sd;      // 8 bytes covering the unit's 8 packed bases
-  uint32_t seg;   // segment | active << 16
-  uint32_t jj;    // window unit (positions 8*jj .. 8*jj+7)
-  // Everything the plain (unstitched) path needs, packed at issue time so that processing
-  // does not touch the segment list again:
-  //   0..7 jj | 8..15 valid-base mask | 16..17 qual byte shift | 18..20 nibble shift |
-  //   21 strand slot
-  uint32_t meta;
+  uint32_t sd[5];                  // 20 bytes covering the unit's 32 packed bases
+  uint32_t qd[NEED_Q ? 9 : 1];     // 36 bytes covering the unit's 32 quals
+  uint32_t mask;                   // valid positions of the unit
+  uint32_t meta;                   // 0..5 window unit | 6..8 nibble shift | 9..10 qual byte shift |
+                                   // 11 strand slot | 16 active
+  uint32_t seg;                    // segment (stitched / clipped paths)
 };
 
 // Byte offsets, inside a record's payload, of the unit's first qual / first packed base.
@@ -283,103 +292,143 @@ __device__ __forceinline__ void unit_offsets(uint32_t lseqnc, int32_t b0, int32_
 // Loads are issued unconditionally (inactive lanes read the start of the payload buffer) so
 // that every issue is the same number of VMEM instructions and the counted vmcnt waits stay
 // exact.  NEED_Q = false (min_base_qual 0, no stitching: every base passes the quality rule,
-// pileup.go:227) skips the qual load altogether.
+// pileup.go:227) skips the qual loads altogether.
 template <bool NEED_Q, bool EXTRA>
 __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<EXTRA>& S, uint32_t t,
-                                           uint32_t T, UnitLoad& L) {
+                                           uint32_t T, uint32_t R, UnitLoad<NEED_Q>& L) {
+  // Slot order: neighbouring segments overlap on the genome, and lanes of one instruction
+  // that add to the same counter serialise.  Groups of 8 consecutive slots (about one
+  // segment) are dealt out column-wise over an 8 x R grid, so the 8 groups a wave holds are
+  // R groups = an eighth of the round's units apart.
+  {
+    // (the LDS works on half-waves: lanes 0-31 take columns 0,2,4,6 - a quarter of the round
+    // apart, 8 units = 8 banks at 30x - and lanes 32-63 columns 1,3,5,7)
+    const uint32_t c = t >> 3, a = c >> 3, b = ((c & 3u) << 1) | ((c >> 2) & 1u);
+    t = a < R ? (((b * R + a) << 3) | (t & 7u)) : T;  // rows past R hold no slots
+  }
   bool in = t < T;
   uint32_t s = S.owner[in ? t : 0];
   if (s == 0xffffu) { in = false; s = 0; }
   const uint4 r = S.seg[s];
   const uint32_t u = t - (r.z & 0x7fffu);
-  const uint32_t jj = ((r.z >> 16) & 0xffu) + u;
-  uint32_t mask = (u == 0 ? (r.y >> 8) : 0xffu) & (u == (r.y >> 24) ? (r.y >> 16) : 0xffu) & 0xffu;
-  mask = in ? mask : 0u;
-  L.jj = in ? jj : 0u;
-  L.seg = s | (in ? 0x10000u : 0u);
-  L.meta = L.jj | (mask << 8) | (((r.z >> 24) & 3u) << 16) | (((r.y >> 3) & 7u) << 18) | (((r.y >> 6) & 1u) << 21);
-  uint64_t off = (((uint64_t)(r.y & 7u) << 32) | r.x) + 4u * u;
+  const uint32_t jj = ((r.z >> 16) & 0x3fu) + u;
+  uint32_t mask = (u == 0 ? 0xffffffffu << ((r.y >> 8) & 31u) : 0xffffffffu) &
+                  (u == ((r.y >> 24) & 0x3fu) ? 0xffffffffu >> (31u - ((r.y >> 13) & 31u)) : 0xffffffffu);
+  L.mask = in ? mask : 0u;
+  L.seg = s;
+  L.meta = (in ? jj | 0x10000u : 0u) | (((r.y >> 3) & 7u) << 6) | (((r.z >> 24) & 3u) << 9) |
+           (((r.y >> 6) & 1u) << 11);
+  uint64_t off = (((uint64_t)(r.y & 7u) << 32) | r.x) + 16u * u;
   if (!in) off = 0;
   const uint8_t* sp = P.blob + off;
   if constexpr (NEED_Q) {
-    const int64_t qd = in ? (int64_t)(int32_t)r.w + 4 * (int64_t)u : 0;
-    L.qd = *(const u32x3a*)(sp + qd);
+    const uint8_t* qp = sp + (in ? (int64_t)(int32_t)r.w + 16 * (int64_t)u : 0);
+    const u32x4a q0 = *(const u32x4a*)qp;
+    const u32x4a q1 = *(const u32x4a*)(qp + 16);
+    L.qd[8] = *(const uint32_t*)(qp + 32);
+    L.qd[0] = q0.x; L.qd[1] = q0.y; L.qd[2] = q0.z; L.qd[3] = q0.w;
+    L.qd[4] = q1.x; L.qd[5] = q1.y; L.qd[6] = q1.z; L.qd[7] = q1.w;
   }
-  L.sd = *(const u32x2a*)sp;
+  const u32x4a s0 = *(const u32x4a*)sp;
+  L.sd[4] = *(const uint32_t*)(sp + 16);
+  L.sd[0] = s0.x; L.sd[1] = s0.y; L.sd[2] = s0.z; L.sd[3] = s0.w;
 }
 
-// The plain path: no stitching.  The 8 plane codes of a unit are computed together on the
-// nibble-packed bases (SWAR), so the per-base cost is two extractions, one multiply-add and
-// the LDS atomic.
+// BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i (this is
+// the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
+__device__ __forceinline__ uint32_t swap_nibbles(uint32_t v) {
+  return ((v & 0x0f0f0f0fu) << 4) | ((v >> 4) & 0x0f0f0f0fu);
+}
+
+// The plain path: no stitching.  The unit's 32 positions are handled as 4 groups of 8; the 8
+// plane codes of a group are computed together on the nibble-packed bases (SWAR), so the
+// per-base cost is two extractions, one multiply-add and the LDS atomic.
 //   code c: A 0, C 1, G 2, T 3, X 4, depth-only 5  ->  plane 2c + strand slot
 // Seq8ToEnumTable (pileup/common.go:66): a nibble with exactly one bit set is a base
 // (log2 = its code); every other value is X.  A base failing the quality rule goes to the
 // depth-only planes, X is counted regardless (addBase, pileup.go:223-231).
 template <bool CLIP, bool MINQ0>
 __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockSharedT<CLIP>& B,
-                                                   const UnitLoad& L) {
+                                                   const UnitLoad<!MINQ0>& L) {
   constexpr uint32_t M1 = 0x11111111u;
   const uint32_t meta = L.meta;
-  // BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i
-  // (this is the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
-  const uint32_t x0 = ((L.sd.x & 0x0f0f0f0fu) << 4) | ((L.sd.x >> 4) & 0x0f0f0f0fu);
-  const uint32_t x1 = ((L.sd.y & 0x0f0f0f0fu) << 4) | ((L.sd.y >> 4) & 0x0f0f0f0fu);
-  const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, (meta >> 16) & 0x1cu);  // 4 * noff
-  const uint32_t t1 = sw >> 1, t2 = sw >> 2, t3 = sw >> 3;
-  const uint32_t lb0 = (t1 | t3) & M1, lb1 = (t2 | t3) & M1;       // log2 of a one-hot nibble
-  const uint32_t x = sw ^ t1, a = sw & t1;                          // pair parity / pair full
-  const uint32_t oh = (x ^ (x >> 2)) & ~(a | (a >> 2)) & M1;        // exactly one bit set
-  const uint32_t oh3 = oh | (oh << 1);
-  uint32_t cw = ((lb0 | (lb1 << 1)) & oh3) | ((oh ^ M1) << 2);      // one-hot ? log2 : 4 (X)
-  if constexpr (!MINQ0) {
-    // quality rule on the 8 quals at once: byte flag 0x80 = qual >= min_base_qual
-    const uint32_t qsh = (meta >> 16) & 3u;
-    const uint32_t qlo = __builtin_amdgcn_alignbyte(L.qd.y, L.qd.x, qsh);
-    const uint32_t qhi = __builtin_amdgcn_alignbyte(L.qd.z, L.qd.y, qsh);
-    constexpr uint32_t H = 0x80808080u;
-    const uint32_t minq4 = (uint32_t)P.min_base_qual * 0x01010101u;
-    uint32_t mlo = (((qlo | H) - minq4) | qlo) & H;
-    uint32_t mhi = (((qhi | H) - minq4) | qhi) & H;
-    // byte flags (bits 7,15,23,31) -> nibble-spaced flags (bits 7,11,15,19)
-    mlo = (mlo | (mlo >> 4)) & 0x08800880u;
-    mlo = (mlo | (mlo >> 8)) & 0x00088880u;
-    mhi = (mhi | (mhi >> 4)) & 0x08800880u;
-    mhi = (mhi | (mhi >> 8)) & 0x00088880u;
-    uint32_t pn = (mlo >> 7) | (mhi << 9);  // bit 4k = base k passes
-    if constexpr (CLIP) {
-      // clipQuals (pileup_support.go:51-69): the first and last `clip` bases of the read have
-      // quality 2
-      const uint32_t sg = L.seg & 0xffffu;
-      const int32_t b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + ((int32_t)((meta & 0xffu) * 8) - B.ex.s_ref[sg]);
-      const int32_t lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
-      const int32_t clip = P.clip;
-      int32_t nlo = clip - b0;                 // bases k < nlo are clipped
-      int32_t nhi = lseq - clip - b0;          // bases k >= nhi are clipped
-      if (2 * clip >= lseq) nlo = 8;
-      nlo = nlo < 0 ? 0 : (nlo > 8 ? 8 : nlo);
-      nhi = nhi < 0 ? 0 : (nhi > 8 ? 8 : nhi);
-      const uint32_t lo_m = nlo >= 8 ? M1 : (M1 & ((1u << (4 * nlo)) - 1u));
-      const uint32_t hi_m = nhi >= 8 ? 0u : (M1 & ~((1u << (4 * nhi)) - 1u));
-      const uint32_t cm = lo_m | hi_m;
-      pn = (uint32_t)P.min_base_qual <= 2u ? (pn | cm) : (pn & ~cm);
-    }
-    const uint32_t pn15 = (pn << 4) - pn;   // 0xf per passing base
-    const uint32_t cf = 0x44444444u | oh;          // failing: base -> depth-only (5), X stays X (4)
-    cw = (cw & pn15) | (cf & ~pn15);
-  }
-  const uint32_t cbase = ((meta & 0xffu) + ((meta >> 21) & 1u) * (uint32_t)kStride) * 4u;
+  const uint32_t jj = meta & 0x3fu;
+  uint32_t x[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) x[i] = swap_nibbles(L.sd[i]);
+  const uint32_t nsh = (meta >> 4) & 0x1cu;  // 4 * nibble shift
+  const uint32_t cbase = (jj + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
   char* const lds = (char*)B.cnt;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint32_t c = (cw >> (4 * k)) & 7u;
-    const uint32_t val = (meta >> (8 + k)) & 1u;
-    atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + cbase + k * kSub * 4), val);
+  for (int m = 0; m < 4; m++) {
+    const uint32_t sw = __builtin_amdgcn_alignbit(x[m + 1], x[m], nsh);
+    const uint32_t t1 = sw >> 1, t2 = sw >> 2, t3 = sw >> 3;
+    const uint32_t lb0 = (t1 | t3) & M1, lb1 = (t2 | t3) & M1;       // log2 of a one-hot nibble
+    const uint32_t xx = sw ^ t1, a = sw & t1;                         // pair parity / pair full
+    const uint32_t oh = (xx ^ (xx >> 2)) & ~(a | (a >> 2)) & M1;      // exactly one bit set
+    const uint32_t oh3 = oh | (oh << 1);
+    uint32_t cw = ((lb0 | (lb1 << 1)) & oh3) | ((oh ^ M1) << 2);      // one-hot ? log2 : 4 (X)
+    if constexpr (!MINQ0) {
+      // quality rule on the 8 quals at once: byte flag 0x80 = qual >= min_base_qual
+      const uint32_t qsh = (meta >> 9) & 3u;
+      const uint32_t qlo = __builtin_amdgcn_alignbyte(L.qd[2 * m + 1], L.qd[2 * m], qsh);
+      const uint32_t qhi = __builtin_amdgcn_alignbyte(L.qd[2 * m + 2], L.qd[2 * m + 1], qsh);
+      constexpr uint32_t H = 0x80808080u;
+      const uint32_t minq4 = (uint32_t)P.min_base_qual * 0x01010101u;
+      uint32_t mlo = (((qlo | H) - minq4) | qlo) & H;
+      uint32_t mhi = (((qhi | H) - minq4) | qhi) & H;
+      // byte flags (bits 7,15,23,31) -> nibble-spaced flags (bits 7,11,15,19)
+      mlo = (mlo | (mlo >> 4)) & 0x08800880u;
+      mlo = (mlo | (mlo >> 8)) & 0x00088880u;
+      mhi = (mhi | (mhi >> 4)) & 0x08800880u;
+      mhi = (mhi | (mhi >> 8)) & 0x00088880u;
+      uint32_t pn = (mlo >> 7) | (mhi << 9);  // bit 4k = base k passes
+      if constexpr (CLIP) {
+        // clipQuals (pileup_support.go:51-69): the first and last `clip` bases of the read
+        // have quality 2
+        const uint32_t sg = L.seg;
+        const int32_t b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + ((int32_t)((4 * jj + m) * 8) - B.ex.s_ref[sg]);
+        const int32_t lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
+        const int32_t clip = P.clip;
+        int32_t nlo = clip - b0;                 // bases k < nlo are clipped
+        int32_t nhi = lseq - clip - b0;          // bases k >= nhi are clipped
+        if (2 * clip >= lseq) nlo = 8;
+        nlo = nlo < 0 ? 0 : (nlo > 8 ? 8 : nlo);
+        nhi = nhi < 0 ? 0 : (nhi > 8 ? 8 : nhi);
+        const uint32_t lo_m = nlo >= 8 ? M1 : (M1 & ((1u << (4 * nlo)) - 1u));
+        const uint32_t hi_m = nhi >= 8 ? 0u : (M1 & ~((1u << (4 * nhi)) - 1u));
+        const uint32_t cm = lo_m | hi_m;
+        pn = (uint32_t)P.min_base_qual <= 2u ? (pn | cm) : (pn & ~cm);
+      }
+      const uint32_t pn15 = (pn << 4) - pn;     // 0xf per passing base
+      const uint32_t cf = 0x44444444u | oh;     // failing: base -> depth-only (5), X stays X (4)
+      cw = (cw & pn15) | (cf & ~pn15);
+    }
+    // lanes without a unit (or without a valid base in this group) sit the atomics out:
+    // they would all add 0 to one address and serialise the whole instruction
+    if ((L.mask >> (8 * m)) & 0xffu) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t c = (cw >> (4 * k)) & 7u;
+        const uint32_t val = (L.mask >> (8 * m + k)) & 1u;
+        atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + cbase + (8 * m + k) * kSub * 4), val);
+      }
+    }
   }
 }
 
+// 8 positions of a unit, as the stitched path handles them
+struct Group8 {
+  uint32_t q0, q1, q2;  // 12 bytes covering the 8 quals
+  uint32_t s0, s1;      // 8 bytes covering the 8 packed bases
+  uint32_t seg;         // segment | active << 16
+  uint32_t jj;          // window positions 8*jj .. 8*jj+7
+  uint32_t sslot;
+};
+
 template <bool STITCH, bool CLIP>
 __device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT<true>& B,
-                                             const UnitLoad& L, uint32_t wlen, int32_t g0) {
+                                             const Group8& L, uint32_t wlen, int32_t g0) {
   const bool in = (L.seg & 0x10000u) != 0;
   const uint32_t s = L.seg & 0xffffu;
   const int32_t sref = B.ex.s_ref[s];
@@ -404,15 +453,12 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT
   mask = in ? mask : 0u;
   // 8 quals and 8 nibbles, realigned to the unit
   const uint32_t qsh = (uint32_t)qoff & 3u;
-  const uint32_t qlo = __builtin_amdgcn_alignbyte(L.qd.y, L.qd.x, qsh);
-  const uint32_t qhi = __builtin_amdgcn_alignbyte(L.qd.z, L.qd.y, qsh);
-  // BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i
-  // (this is the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
-  const uint32_t x0 = ((L.sd.x & 0x0f0f0f0fu) << 4) | ((L.sd.x >> 4) & 0x0f0f0f0fu);
-  const uint32_t x1 = ((L.sd.y & 0x0f0f0f0fu) << 4) | ((L.sd.y >> 4) & 0x0f0f0f0fu);
+  const uint32_t qlo = __builtin_amdgcn_alignbyte(L.q1, L.q0, qsh);
+  const uint32_t qhi = __builtin_amdgcn_alignbyte(L.q2, L.q1, qsh);
+  const uint32_t x0 = swap_nibbles(L.s0), x1 = swap_nibbles(L.s1);
   const uint32_t noff = 2u * ((uint32_t)soff & 3u) + ((uint32_t)b0 & 1u);
   const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, 4u * noff);
-  uint32_t sslot_u = (L.meta >> 21) & 1u;
+  uint32_t sslot_u = L.sslot;
   const uint32_t minq = (uint32_t)P.min_base_qual;
   const int32_t clip = P.clip;
 
@@ -435,7 +481,7 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT
       }
     }
   }
-  uint32_t* const cb = B.cnt + sslot_u * kStride + L.jj;
+  uint32_t* const cb = B.cnt + sslot_u * kStride + (L.jj >> 2) + 8u * (L.jj & 3u) * kSub;
 
 #ifndef BP_EXP_KMAX
 #define BP_EXP_KMAX 8
@@ -490,9 +536,22 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT
 
 template <bool STITCH, bool CLIP, bool MINQ0>
 __device__ __forceinline__ void unit(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
-                                     const UnitLoad& L, uint32_t wlen, int32_t g0) {
-  if constexpr (STITCH) process_unit<true, CLIP>(P, B, L, wlen, g0);
-  else process_unit_plain<CLIP, MINQ0>(P, B, L);
+                                     const UnitLoad<STITCH || !MINQ0>& L, uint32_t wlen, int32_t g0) {
+  if constexpr (STITCH) {
+    const uint32_t act = (L.meta & 0x10000u);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      Group8 g;
+      g.q0 = L.qd[2 * m]; g.q1 = L.qd[2 * m + 1]; g.q2 = L.qd[2 * m + 2];
+      g.s0 = L.sd[m]; g.s1 = L.sd[m + 1];
+      g.seg = L.seg | act;
+      g.jj = 4u * (L.meta & 0x3fu) + m;
+      g.sslot = (L.meta >> 11) & 1u;
+      process_unit<true, CLIP>(P, B, g, wlen, g0);
+    }
+  } else {
+    process_unit_plain<CLIP, MINQ0>(P, B, L);
+  }
 }
 
 // Workgroup = kWinPerBlock consecutive windows, processed one after the other:
@@ -680,11 +739,11 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       {
         unsigned long long a_issue = 0, a_wait = 0, a_proc = 0;
         for (uint32_t tb = wbase; tb < T; tb += kBlock) {
-          UnitLoad L1;
+          UnitLoad<NEED_Q> L1;
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t0 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          issue_unit<NEED_Q>(P, S, tb + (tid & 63), T, L1);
+          issue_unit<NEED_Q>(P, S, tb + (tid & 63), T, (T + 63) / 64, L1);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -707,28 +766,30 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 #else
       {
         // Every thread runs n_it unit slots (block-uniform).  The steady-state loop has no
-        // branch in its body, so the compiler's counted vmcnt waits keep kDepth units' loads
-        // in flight; only the drain after the loop is conservative.
-        const uint32_t n_it = (T + kBlock - 1) / kBlock;
-        UnitLoad L[kDepth];
+        // branch in its body, so the compiler's counted vmcnt waits keep kD units' loads in
+        // flight; at 30x a window is 2-3 units per thread and the loop body rarely runs.
+        constexpr int kD = NEED_Q ? kDepthQ : kDepth;
+        const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
+        const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
+        UnitLoad<NEED_Q> L[kD];
         uint32_t t = (uint32_t)tid;
 #pragma unroll
-        for (int d = 0; d < kDepth; d++) {
-          issue_unit<NEED_Q>(P, S, t, T, L[d]);
+        for (int d = 0; d < kD; d++) {
+          issue_unit<NEED_Q>(P, S, t, T, R, L[d]);
           t += kBlock;
         }
         uint32_t it = 0;
-        for (; it + kDepth <= n_it; it += kDepth) {
+        for (; it + kD < n_it; it += kD) {
 #pragma unroll
-          for (int d = 0; d < kDepth; d++) {
+          for (int d = 0; d < kD; d++) {
             unit<STITCH, CLIP, MINQ0>(P, S, L[d], wlen, g0);
-            issue_unit<NEED_Q>(P, S, t, T, L[d]);
+            issue_unit<NEED_Q>(P, S, t, T, R, L[d]);
             t += kBlock;
           }
         }
         const uint32_t rem = n_it - it;
 #pragma unroll
-        for (int d = 0; d < kDepth - 1; d++)
+        for (int d = 0; d < kD; d++)
           if ((uint32_t)d < rem) unit<STITCH, CLIP, MINQ0>(P, S, L[d], wlen, g0);
       }
 #endif
@@ -742,7 +803,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     for (uint32_t p = tid; p < (uint32_t)kW; p += kBlock) {
       uint32_t v[kPlanes];
       uint32_t d = 0;
-      uint32_t* const cp = S.cnt + (p & 7u) * kSub + (p >> 3);
+      uint32_t* const cp = S.cnt + (p & 31u) * kSub + (p >> 5);
 #pragma unroll
       for (int c = 0; c < kPlanes; c++) {
         v[c] = cp[c * kStride];

@@ -210,23 +210,72 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
   return v;
 }
 
-// Admit one M-segment per lane into the round's list; called by every lane of the wave
-// (want = this lane has a segment).  Slots are handed out with a wave prefix sum and ONE
-// LDS atomic per wave on a packed (segments << 32 | units) counter, so unit slots grow with
-// the segment index.  Returns false for a lane whose segment did not fit this round: the
+// One M-segment of a record, relative to the window.
+struct SegIn {
+  int32_t sref;   // first window position (may be < 0)
+  int32_t len;
+  int32_t q0;     // read index of its first base
+};
+
+// Window positions [s1, e1) and unit range of a segment; false when nothing of it is inside.
+__device__ __forceinline__ bool seg_extent(const SegIn& g, uint32_t wlen, int32_t& s1, int32_t& e1,
+                                           uint32_t& jlo, uint32_t& U) {
+  s1 = g.sref > 0 ? g.sref : 0;
+  e1 = (int64_t)g.sref + g.len < (int64_t)wlen ? g.sref + g.len : (int32_t)wlen;
+  if (e1 <= s1) { jlo = 0; U = 0; return false; }
+  jlo = (uint32_t)s1 >> 5;
+  U = ((uint32_t)(e1 - 1) >> 5) - jlo + 1;
+  return true;
+}
+
+template <bool EXTRA>
+__device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, uint32_t us, const SegIn& g,
+                                          int32_t s1, int32_t e1, uint32_t jlo, uint32_t U, uint32_t blob,
+                                          uint32_t lseqnc, uint32_t sslot, int32_t rec) {
+  // byte offsets inside the record payload [cigar padded to even][qual 8*Ur][seq 4*Ur]
+  const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
+  const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
+  const int32_t d = g.q0 - g.sref;                       // read index of window position 0
+  const int32_t b_first = d + (int32_t)(jlo * 32);       // read index of the first unit's base 0
+  const int32_t qo = cigb + b_first;                     // >= -24: the payload buffer starts with a pad
+  const int32_t so = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b_first >> 1);
+  const uint64_t sa = (uint64_t)blob * 8 + (uint64_t)(uint32_t)(so & ~3);
+  const uint32_t noff = 2u * ((uint32_t)so & 3u) + ((uint32_t)d & 1u);
+  uint4 r;
+  r.x = (uint32_t)sa;
+  r.y = (uint32_t)(sa >> 32) | (noff << 3) | (sslot << 6) | (((uint32_t)s1 & 31u) << 8) |
+        (((uint32_t)(e1 - 1) & 31u) << 13) | ((U - 1) << 24);
+  r.z = us | (jlo << 16) | (((uint32_t)qo & 3u) << 24);
+  r.w = (uint32_t)((qo & ~3) - (so & ~3));
+  S.seg[idx] = r;
+  if constexpr (EXTRA) {
+    S.ex.s_ref[idx] = g.sref;
+    S.ex.s_lenq0[idx] = (uint32_t)g.len | ((uint32_t)g.q0 << 16);
+    S.ex.s_lseqnc[idx] = lseqnc;
+    S.ex.s_rec[idx] = rec;
+  }
+  for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
+}
+
+// Admit up to two M-segments per lane (A, then B) into the round's list; called by every lane
+// of the wave.  Slots are handed out with a wave prefix sum and ONE LDS atomic per wave on a
+// packed (segments << 32 | units) counter, so unit slots grow with the segment index.
+// Returns false for a lane whose segments did not fit this round (it got neither): the
 // caller keeps its cursor and retries next round.
 template <bool EXTRA>
-__device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool want, int32_t sref, int32_t len,
-                                          int32_t q0, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
+__device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
+                                          const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
                                           uint32_t sslot, int32_t rec) {
-  const int32_t s1 = sref > 0 ? sref : 0;
-  const int32_t e1 = (int64_t)sref + len < (int64_t)wlen ? sref + len : (int32_t)wlen;
-  const bool real = want && e1 > s1;  // clipped-away segments need no slot
-  const uint32_t jlo = (uint32_t)s1 >> 5;
-  const uint32_t U = real ? (((uint32_t)(e1 - 1) >> 5) - jlo + 1) : 0u;
-  // inclusive prefix sums of (1, U) over the wave, packed as count << 16 | units
-  // (a wave adds at most 64 segments x kW/32 units: no carry between the fields)
-  const uint32_t mine = real ? (0x10000u | U) : 0u;
+  int32_t s1A, e1A, s1B, e1B;
+  uint32_t jloA, UA, jloB, UB;
+  const bool realA = seg_extent(A, wlen, s1A, e1A, jloA, UA) && wantA;  // clipped-away segments need no slot
+  const bool realB = seg_extent(B, wlen, s1B, e1B, jloB, UB) && wantB;
+  if (!realA) UA = 0;
+  if (!realB) UB = 0;
+  const uint32_t nseg = (realA ? 1u : 0u) + (realB ? 1u : 0u), U = UA + UB;
+  // inclusive prefix sums of (segments, units) over the wave, packed as count << 16 | units
+  // (a wave adds at most 128 segments x kW/32 units: no carry between the fields)
+  const uint32_t mine = (nseg << 16) | U;
   const uint32_t incl = wave_inclusive_scan(mine);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   unsigned long long base = 0;
@@ -236,37 +285,14 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool want, int
   const uint32_t base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
   const uint32_t excl = incl - mine;
   const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
-  const bool ok = idx < (uint32_t)kSegCap && us < (uint32_t)kUnitCap && us + U <= (uint32_t)kUnitCap;
-  if (real) {
-    if (ok) {
-      // byte offsets inside the record payload [cigar padded to even][qual 8*Ur][seq 4*Ur]
-      const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
-      const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
-      const int32_t d = q0 - sref;                       // read index of window position 0
-      const int32_t b_first = d + (int32_t)(jlo * 32);   // read index of the first unit's base 0
-      const int32_t qo = cigb + b_first;                 // >= -24: the payload buffer starts with a pad
-      const int32_t so = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b_first >> 1);
-      const uint64_t sa = (uint64_t)blob * 8 + (uint64_t)(uint32_t)(so & ~3);
-      const uint32_t noff = 2u * ((uint32_t)so & 3u) + ((uint32_t)d & 1u);
-      uint4 r;
-      r.x = (uint32_t)sa;
-      r.y = (uint32_t)(sa >> 32) | (noff << 3) | (sslot << 6) | (((uint32_t)s1 & 31u) << 8) |
-            (((uint32_t)(e1 - 1) & 31u) << 13) | ((U - 1) << 24);
-      r.z = us | (jlo << 16) | (((uint32_t)qo & 3u) << 24);
-      r.w = (uint32_t)((qo & ~3) - (so & ~3));
-      S.seg[idx] = r;
-      if constexpr (EXTRA) {
-        S.ex.s_ref[idx] = sref;
-        S.ex.s_lenq0[idx] = (uint32_t)len | ((uint32_t)q0 << 16);
-        S.ex.s_lseqnc[idx] = lseqnc;
-        S.ex.s_rec[idx] = rec;
-      }
-      for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
-    } else {
-      for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
-    }
+  const bool ok = idx + nseg <= (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
+  if (ok) {
+    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, sslot, rec);
+    if (realB) write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, sslot, rec);
+  } else {
+    for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
   }
-  return ok || !real;
+  return ok;
 }
 
 // One unit in flight: the loaded bytes and everything processing needs, so that the plain
@@ -554,6 +580,36 @@ __device__ __forceinline__ void unit(const KernelParams& P, BlockSharedT<STITCH 
   }
 }
 
+// Advance the CIGAR cursor (c, r, q) = (op index, window position, read index) to the next M
+// op that starts inside the window and step past it; false when there is none.
+__device__ __forceinline__ bool next_m_op(const uint32_t* cg, uint32_t cg0, uint32_t cg1, uint32_t cg2,
+                                          uint32_t n_cigar, uint32_t wlen, uint32_t& c, int32_t& r,
+                                          int32_t& q, int32_t& sref, int32_t& slen, int32_t& sq0) {
+  while (c < n_cigar) {
+    // the first three ops travel in the core; longer CIGARs continue in the payload
+    const uint32_t cop = c == 0 ? cg0 : c == 1 ? cg1 : c == 2 ? cg2 : cg[c];
+    const uint32_t op = cop & 15u;
+    const int32_t len = (int32_t)(cop >> 4);
+    c++;
+    if (op == 0) {
+      sref = r;
+      slen = len;
+      sq0 = q;
+      r += len;
+      q += len;
+      if (r >= (int32_t)wlen) c = n_cigar;
+      return true;
+    }
+    // I, S consume the read; D, N the reference; H nothing; anything else ends the walk (the
+    // host rejected reachable bad ops, pileup.go:355-359).  Written as selects: with
+    // branches the compiler spills r and q to a scratch array indexed by the op class.
+    q += (op == 1 || op == 4) ? len : 0;
+    r += (op == 2 || op == 3) ? len : 0;
+    if (op > 5 || r >= (int32_t)wlen) c = n_cigar;
+  }
+  return false;
+}
+
 // Workgroup = kWinPerBlock consecutive windows, processed one after the other:
 //   phase 1  thread = record: read filters, CIGAR -> M-segments clipped to the window
 //   phase 2  thread = unit:   counts into the LDS planes
@@ -646,55 +702,43 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         qq = 0;
         have = true;
       }
-      // CIGAR walk (pileup.go:275-363): every M op is one segment; the wave emits one segment
-      // per lane per step, all lanes together
+      // CIGAR walk (pileup.go:275-363): every M op is one segment; the wave admits up to two
+      // segments per lane per step, all lanes together
       bool more = has_rec && keep, failed = false;
       for (;;) {
-        bool want = false;
-        int32_t seg_len = 0, seg_q0 = 0;
+        bool wantA = false, wantB = false;
+        SegIn A = {0, 0, 0}, B = {0, 0, 0};
+        uint32_t cB = 0;              // cursor after the last segment taken
+        int32_t rrB = 0, qqB = 0;
         if (more) {
           if (aux & AUX_SIMPLE) {
-            want = true;
-            seg_len = (int32_t)span;
+            wantA = true;
+            A.sref = rr;
+            A.len = (int32_t)span;
           } else {
             const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
-            while (c_cur < n_cigar) {
-              // the first three ops travel in the core; longer CIGARs continue in the payload
-              const uint32_t cop = c_cur == 0 ? cg0 : c_cur == 1 ? cg1 : c_cur == 2 ? cg2 : cg[c_cur];
-              const uint32_t op = cop & 15u;
-              const int32_t len = (int32_t)(cop >> 4);
-              if (op == 0) {
-                want = true;
-                seg_len = len;
-                seg_q0 = qq;
-                break;
-              } else if (op == 1 || op == 4) {
-                qq += len;
-              } else if (op == 2 || op == 3) {
-                rr += len;
-              } else if (op != 5) {
-                c_cur = n_cigar;  // host rejected reachable bad ops (pileup.go:355-359)
-                break;
-              }
-              c_cur++;
-              if (rr >= (int32_t)wlen) c_cur = n_cigar;
-            }
-            if (!want) more = false;
+            uint32_t c = c_cur;
+            int32_t r_ = rr, q_ = qq;
+            int32_t sA = 0, lA = 0, qA = 0, sB = 0, lB = 0, qB = 0;
+            wantA = next_m_op(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, sA, lA, qA);
+            if (wantA) wantB = next_m_op(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, sB, lB, qB);
+            A.sref = sA; A.len = lA; A.q0 = qA;
+            B.sref = sB; B.len = lB; B.q0 = qB;
+            cB = c; rrB = r_; qqB = q_;
+            if (!wantA) more = false;
           }
         }
-        if (!__any(want)) break;
-        const bool ok = emit_wave(S, want, rr, seg_len, seg_q0, wlen, blob, lseqnc, sslot, rec);
-        if (want) {
+        if (!__any(wantA)) break;
+        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec);
+        if (wantA) {
           if (!ok) {
             failed = true;
             more = false;
           } else if (aux & AUX_SIMPLE) {
             more = false;
           } else {
-            rr += seg_len;
-            qq += seg_len;
-            c_cur++;
-            if (rr >= (int32_t)wlen) more = false;
+            c_cur = cB; rr = rrB; qq = qqB;
+            more = c_cur < n_cigar;
           }
         }
       }

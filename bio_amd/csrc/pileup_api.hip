@@ -614,7 +614,12 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
         memset(d + l, 0, (size_t)U * 8 - l);
         d += (size_t)U * 8;
         const uint32_t sb = (l + 1) / 2;
-        memcpy(d, b->seq + b->seq_off[i], sb);
+        // device layout keeps the first base of a byte in the LOW nibble (BAM: high), so 8
+        // bases are one little-endian dword with base k at bits 4k
+        {
+          const uint8_t* sp = b->seq + b->seq_off[i];
+          for (uint32_t x = 0; x < sb; x++) d[x] = (uint8_t)((sp[x] << 4) | (sp[x] >> 4));
+        }
         const uint64_t tail = blob_bytes(n_cigar, l) - (uint64_t)ncp * 4 - (uint64_t)U * 8 - sb;
         memset(d + sb, 0, (size_t)tail);
         local += 32 + 4 * (int64_t)n_cigar + (l + 1) / 2 + l;

@@ -360,12 +360,6 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
   L.sd[0] = s0.x; L.sd[1] = s0.y; L.sd[2] = s0.z; L.sd[3] = s0.w;
 }
 
-// BAM packs the first base in the high nibble: swap nibbles so base i sits at bit 4i (this is
-// the unpack that biosimd.UnpackSeq does on the CPU, firstread.go:64)
-__device__ __forceinline__ uint32_t swap_nibbles(uint32_t v) {
-  return ((v & 0x0f0f0f0fu) << 4) | ((v >> 4) & 0x0f0f0f0fu);
-}
-
 // The plain path: no stitching.  The unit's 32 positions are handled as 4 groups of 8; the 8
 // plane codes of a group are computed together on the nibble-packed bases (SWAR), so the
 // per-base cost is two extractions, one multiply-add and the LDS atomic.
@@ -379,21 +373,20 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
   constexpr uint32_t M1 = 0x11111111u;
   const uint32_t meta = L.meta;
   const uint32_t jj = meta & 0x3fu;
-  uint32_t x[5];
-#pragma unroll
-  for (int i = 0; i < 5; i++) x[i] = swap_nibbles(L.sd[i]);
+  const uint32_t* const x = L.sd;  // base k of a dword at bits 4k (the packer stores it that way)
   const uint32_t nsh = (meta >> 4) & 0x1cu;  // 4 * nibble shift
   const uint32_t cbase = (jj + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
   char* const lds = (char*)B.cnt;
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     const uint32_t sw = __builtin_amdgcn_alignbit(x[m + 1], x[m], nsh);
-    const uint32_t t1 = sw >> 1, t2 = sw >> 2, t3 = sw >> 3;
-    const uint32_t lb0 = (t1 | t3) & M1, lb1 = (t2 | t3) & M1;       // log2 of a one-hot nibble
+    // log2 of a one-hot nibble n is (n >> 1) - (n >> 3): 1,2,4,8 -> 0,1,2,3
+    const uint32_t t1 = sw >> 1;
+    const uint32_t lg = (t1 & 0x77777777u) - ((sw >> 3) & M1);
     const uint32_t xx = sw ^ t1, a = sw & t1;                         // pair parity / pair full
     const uint32_t oh = (xx ^ (xx >> 2)) & ~(a | (a >> 2)) & M1;      // exactly one bit set
     const uint32_t oh3 = oh | (oh << 1);
-    uint32_t cw = ((lb0 | (lb1 << 1)) & oh3) | ((oh ^ M1) << 2);      // one-hot ? log2 : 4 (X)
+    uint32_t cw = (lg & oh3) + ((oh ^ M1) << 2);                      // one-hot ? log2 : 4 (X)
     if constexpr (!MINQ0) {
       // quality rule on the 8 quals at once: byte flag 0x80 = qual >= min_base_qual
       const uint32_t qsh = (meta >> 9) & 3u;
@@ -481,7 +474,7 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT
   const uint32_t qsh = (uint32_t)qoff & 3u;
   const uint32_t qlo = __builtin_amdgcn_alignbyte(L.q1, L.q0, qsh);
   const uint32_t qhi = __builtin_amdgcn_alignbyte(L.q2, L.q1, qsh);
-  const uint32_t x0 = swap_nibbles(L.s0), x1 = swap_nibbles(L.s1);
+  const uint32_t x0 = L.s0, x1 = L.s1;  // base k of a dword at bits 4k
   const uint32_t noff = 2u * ((uint32_t)soff & 3u) + ((uint32_t)b0 & 1u);
   const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, 4u * noff);
   uint32_t sslot_u = L.sslot;
@@ -539,7 +532,7 @@ __device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT
             const uint32_t mU = ((uint32_t)mc.l_seq + 7) >> 3;
             uint32_t mq = mb[mcig + mi];
             const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
-            const uint32_t mnib = (mi & 1) ? (mbyte & 15u) : (mbyte >> 4);
+            const uint32_t mnib = (mi & 1) ? (mbyte >> 4) : (mbyte & 15u);
             if constexpr (CLIP) mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
             if (mnib * 4 == nsh) {
               if (q >= 96u || mq >= 96u) {

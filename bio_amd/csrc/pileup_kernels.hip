@@ -161,8 +161,7 @@ struct __align__(16) BlockSharedT {
   uint4 seg[kSegCap];
   typename std::conditional<EXTRA, SegExtra, NoExtra>::type ex;
   uint16_t owner[kUnitCap];     // unit slot -> segment
-  unsigned long long n_alloc;   // segments << 32 | units handed out this round
-  uint32_t pad_[2];
+  unsigned long long n_alloc[2];  // segments << 32 | units handed out this round (by round parity)
 };
 
 // Reference position -> read index of record `c` (mate lookup for the overlap rule).
@@ -265,7 +264,7 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
 template <bool EXTRA>
 __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
                                           const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
-                                          uint32_t sslot, int32_t rec) {
+                                          uint32_t sslot, int32_t rec, uint32_t par) {
   int32_t s1A, e1A, s1B, e1B;
   uint32_t jloA, UA, jloB, UB;
   const bool realA = seg_extent(A, wlen, s1A, e1A, jloA, UA) && wantA;  // clipped-away segments need no slot
@@ -280,7 +279,7 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   unsigned long long base = 0;
   if ((threadIdx.x & 63) == 0 && total != 0)
-    base = atomicAdd(&S.n_alloc, ((unsigned long long)(total >> 16) << 32) | (total & 0xffffu));
+    base = atomicAdd(&S.n_alloc[par], ((unsigned long long)(total >> 16) << 32) | (total & 0xffffu));
   const uint32_t base_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
   const uint32_t base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
   const uint32_t excl = incl - mine;
@@ -627,6 +626,9 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   if (w_last > (uint32_t)P.n_windows) w_last = (uint32_t)P.n_windows;
 
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
+  if (tid == 0) S.n_alloc[0] = S.n_alloc[1] = 0;
+  uint32_t par = 0;  // round parity (block-uniform)
+  __syncthreads();
 
   // Everything a window needs from global memory before its unit loads is fetched one
   // window ahead (record range two ahead): window descriptor, record range, this thread's
@@ -661,8 +663,8 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
 
     for (;;) {
-      if (tid == 0) S.n_alloc = 0;
-      __syncthreads();
+      // (no barrier here: the slot counter of this round was reset behind the previous
+      // round's first barrier, and phase 1 touches nothing the flush still reads)
       BP_STAMP(1);
       // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
       const bool has_rec = rec < r1;
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         }
         if (!__any(wantA)) break;
-        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec);
+        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec, par);
         if (wantA) {
           if (!ok) {
             failed = true;
@@ -766,7 +768,8 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 
       // ---- phase 2: thread = unit (8 window positions of one segment); kDepth units in
       // flight per lane
-      const uint32_t n_alloc_u = (uint32_t)S.n_alloc;
+      if (tid == 0) S.n_alloc[par ^ 1u] = 0;  // next round's counter; next touched after the barrier below
+      const uint32_t n_alloc_u = (uint32_t)S.n_alloc[par];
       const uint32_t T = n_alloc_u < (uint32_t)kUnitCap ? n_alloc_u : (uint32_t)kUnitCap;
 #ifdef BP_STAMPS_P2
       const uint32_t wbase = (uint32_t)tid & ~63u;
@@ -831,13 +834,20 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       }
 #endif
       BP_STAMP(4);
+      par ^= 1u;
       if (!__syncthreads_or(pending)) break;
     }
     BP_STAMP(5);
 
     // ---- flush: one lane per position; Depth = sum of the 12 planes (pileup.go:518-570);
     // the planes are zeroed as they are read, ready for the next window
-    for (uint32_t p = tid; p < (uint32_t)kW; p += kBlock) {
+    // The upper half of the waves takes three quarters of the positions: the lower half
+    // holds the records of the next window and moves on to its phase 1 meanwhile.
+    constexpr uint32_t kHalf = kBlock / 2, kQ = (uint32_t)kW / 4;
+    const bool upper = (uint32_t)tid >= kHalf;
+    const uint32_t p_lo = upper ? (uint32_t)tid - kHalf : 3 * kQ + (uint32_t)tid;
+    const uint32_t p_hi = upper ? 3 * kQ : (uint32_t)kW;
+    for (uint32_t p = p_lo; p < p_hi; p += kHalf) {
       uint32_t v[kPlanes];
       uint32_t d = 0;
       uint32_t* const cp = S.cnt + (p & 31u) * kSub + (p >> 5);

@@ -71,6 +71,9 @@ namespace bp {
 #ifndef BP_WINS
 #define BP_WINS 8
 #endif
+#ifndef BP_FLUSH_UPPER
+#define BP_FLUSH_UPPER 8   // eighths of a window's positions flushed by the upper half of the waves
+#endif
 #ifndef BP_MINWAVES
 #define BP_MINWAVES 4
 #endif
@@ -843,10 +846,10 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     // the planes are zeroed as they are read, ready for the next window
     // The upper half of the waves takes three quarters of the positions: the lower half
     // holds the records of the next window and moves on to its phase 1 meanwhile.
-    constexpr uint32_t kHalf = kBlock / 2, kQ = (uint32_t)kW / 4;
+    constexpr uint32_t kHalf = kBlock / 2, kCut = (uint32_t)kW / 8 * BP_FLUSH_UPPER;
     const bool upper = (uint32_t)tid >= kHalf;
-    const uint32_t p_lo = upper ? (uint32_t)tid - kHalf : 3 * kQ + (uint32_t)tid;
-    const uint32_t p_hi = upper ? 3 * kQ : (uint32_t)kW;
+    const uint32_t p_lo = upper ? (uint32_t)tid - kHalf : kCut + (uint32_t)tid;
+    const uint32_t p_hi = upper ? kCut : (uint32_t)kW;
     for (uint32_t p = p_lo; p < p_hi; p += kHalf) {
       uint32_t v[kPlanes];
       uint32_t d = 0;

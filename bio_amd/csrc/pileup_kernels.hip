@@ -74,6 +74,12 @@ namespace bp {
 #ifndef BP_FLUSH_UPPER
 #define BP_FLUSH_UPPER 8   // eighths of a window's positions flushed by the upper half of the waves
 #endif
+#ifndef BP_CHUNK
+#define BP_CHUNK 4      // consecutive unit slots dealt to consecutive lanes
+#endif
+#ifndef BP_PERMUTE
+#define BP_PERMUTE 1
+#endif
 #ifndef BP_MINWAVES
 #define BP_MINWAVES 4
 #endif
@@ -325,14 +331,19 @@ template <bool NEED_Q, bool EXTRA>
 __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<EXTRA>& S, uint32_t t,
                                            uint32_t T, uint32_t R, UnitLoad<NEED_Q>& L) {
   // Slot order: neighbouring segments overlap on the genome, and lanes of one instruction
-  // that add to the same counter serialise.  Groups of 8 consecutive slots (about one
-  // segment) are dealt out column-wise over an 8 x R grid, so the 8 groups a wave holds are
-  // R groups = an eighth of the round's units apart.
+  // that add to the same counter serialise.  Chunks of BP_CHUNK consecutive slots (part of
+  // one segment: distinct units, consecutive banks) are dealt out column-wise over a
+  // (64 / BP_CHUNK) x R grid, so the chunks a wave holds are R chunks apart in slot order:
+  // spread evenly over the round's units, i.e. over the window.
   {
-    // (the LDS works on half-waves: lanes 0-31 take columns 0,2,4,6 - a quarter of the round
-    // apart, 8 units = 8 banks at 30x - and lanes 32-63 columns 1,3,5,7)
-    const uint32_t c = t >> 3, a = c >> 3, b = ((c & 3u) << 1) | ((c >> 2) & 1u);
-    t = a < R ? (((b * R + a) << 3) | (t & 7u)) : T;  // rows past R hold no slots
+    // (the LDS works on half-waves: lanes 0-31 take the even columns and lanes 32-63 the odd
+    // ones, so that each half spans the whole window)
+    constexpr uint32_t kCh = BP_CHUNK, kCols = 64 / kCh;
+#if BP_PERMUTE
+    const uint32_t a = t >> 6, ci = (t & 63u) / kCh;
+    const uint32_t b = ((ci % (kCols / 2)) << 1) | (ci / (kCols / 2));
+    t = a < R ? (((b * R + a) * kCh) | (t & (kCh - 1))) : T;  // rows past R hold no slots
+#endif
   }
   bool in = t < T;
   uint32_t s = S.owner[in ? t : 0];

@@ -13,17 +13,23 @@
 // Mapping (wave64, 512-thread workgroups).  A workgroup owns kWinPerBlock consecutive
 // windows of kW reference positions and walks them one after the other:
 //   phase 1  thread = record.  Read-level filters, then the CIGAR walk turns every M op into
-//            a segment clipped to the window; a wave hands out segment and unit slots with
-//            one shuffle prefix sum and ONE packed 64-bit LDS atomic.
-//   phase 2  thread = unit = the 8 window positions [8j, 8j+8) of one segment: one unaligned
-//            12-byte qual load + one 8-byte packed-base load, realigned in registers, then 8
-//            ds_add_u32 whose addresses differ only by an immediate.  kDepth units are in
-//            flight per lane in a branch-free software pipeline.
-//   flush    thread = position: Depth = sum of the 12 planes, row written with 3 wide
-//            stores, planes zeroed on the way out.
-// The LDS histogram is counter-major (cnt[plane][position]) with position p = 8j + k stored
-// at k*kSub + j (kSub = kW/8 + 4): consecutive lanes hold consecutive units j of the same
-// segment, so the 8 adds of a wave instruction hit consecutive banks whatever the depth.
+//            a segment clipped to the window (two per lane per step); a wave hands out
+//            segment and unit slots with one DPP prefix sum and ONE packed 64-bit LDS atomic,
+//            and leaves a 16-byte record per segment with everything its units need.
+//   phase 2  thread = unit = the 32 window positions [32j, 32j+32) of one segment: a 20-byte
+//            load of packed bases (plus 36 bytes of quals when a quality rule is active),
+//            realigned in registers; the 8 plane codes of 8 bases are computed together
+//            (SWAR on nibbles), then 32 ds_add_u32 whose addresses differ only by an
+//            immediate.  Units are dealt to lanes so that the lanes of one LDS instruction
+//            come from all over the window: reads that overlap on the genome would
+//            otherwise serialise on the same counters.
+//   flush    thread = position (upper half of the waves, while the lower half already runs
+//            phase 1 of the next window): Depth = sum of the 12 planes, row written with 3
+//            wide stores, planes zeroed on the way out.
+// The LDS histogram is counter-major (cnt[plane][position]) with position p = 32j + r stored
+// at r*kSub + j (kSub = kW/32 + 1): consecutive lanes hold consecutive units j of the same
+// segment, so the adds of a wave instruction hit consecutive banks, and so do the 32
+// positions a flush instruction reads.
 //
 // Depth is not accumulated separately: every aligned base adds exactly one counter, either
 // its Counts[base][strand] slot or a "depth only" slot (planes 10/11: base failed the quality
@@ -620,8 +626,9 @@ __device__ __forceinline__ bool next_m_op(const uint32_t* cg, uint32_t cg0, uint
 //   phase 1  thread = record: read filters, CIGAR -> M-segments clipped to the window
 //   phase 2  thread = unit:   counts into the LDS planes
 //   flush    thread = position: Depth + Counts row to HBM, planes zeroed on the way out
-// The record cores of window i+1 are loaded while window i is in phase 2, so the only
-// exposed memory latency per window is that of the unit loads.
+// Two barriers per window (after phase 1, after phase 2).  The record cores of window i+1
+// are loaded while window i is in phase 2, so the only exposed memory latency per window is
+// that of the unit loads.
 template <bool STITCH, bool CLIP, bool MINQ0>
 __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParams P) {
   constexpr bool NEED_Q = STITCH || !MINQ0;
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         }
       }
 
-      // ---- phase 2: thread = unit (8 window positions of one segment); kDepth units in
+      // ---- phase 2: thread = unit (32 window positions of one segment); kDepth units in
       // flight per lane
       if (tid == 0) S.n_alloc[par ^ 1u] = 0;  // next round's counter; next touched after the barrier below
       const uint32_t n_alloc_u = (uint32_t)S.n_alloc[par];

@@ -54,12 +54,15 @@ def _in_bed(bed_sets, ref, p):
     return p in bed_sets.get(ref, ())
 
 
-def pileup(opts, bed, batch, region_filter=None):
+def pileup(opts, bed, batch, region_filter=None, per_read=None):
     """opts: object with clip, flag_exclude, mapq, max_read_len, max_read_span, min_base_qual,
     stitch, ignore_strand, strand_req.  bed: {ref: [[s,e],...]}.  region_filter: optional
     (ref, start, end) = the unpadded single shard of -region mode (only reads whose start lies
     in it are ever seen).  Returns {(ref,pos): [depth, A+,A-,C+,C-,G+,G-,T+,T-,X+,X-]} for every
-    BED position."""
+    BED position.  per_read: optional dict that receives {(ref,pos): [[(dist5p, fraglen, qual,
+    strand), ...] x 4]} (appendBase, pileup.go:235-250; unstitched runs only)."""
+    if per_read is not None and opts.stitch:
+        raise PileupError("stitched per-read features not yet supported")
     bed_sets = {r: set(p for s, e in iv for p in range(s, e)) for r, iv in bed.items()}
     out = {(r, p): [0] * 11 for r, ps in bed_sets.items() for p in ps}
     qst = qual_sum_table()
@@ -123,6 +126,11 @@ def pileup(opts, bed, batch, region_filter=None):
             e = SEQ8_TO_ENUM[nib(i, k)]
             if qual(i, k) >= opts.min_base_qual or e == 4:
                 row[1 + 2 * e + slot] += 1
+                if per_read is not None and e != 4:
+                    lists = per_read.setdefault((int(batch.ref_id[i]), rp), [[], [], [], []])
+                    lists[e].append((k, int(batch.l_seq[i]), qual(i, k),
+                                     get_strand(int(batch.ref_id[i]), int(batch.mate_ref_id[i]),
+                                                int(batch.flags[i]))))
 
     def pair(b, a, slot):
         """b = later record (found a in the table); strand slot is b's."""

@@ -482,9 +482,18 @@ static void fr_free(firstreads* f) {
 }
 
 /* ---------------------------------------------------------------- job state */
+/* PerReadFeatures (row.go:22-31) */
+typedef struct {
+  uint16_t dist5p, fraglen;
+  uint8_t qual, strand;
+} orc_feat;
+
 typedef struct {
   uint32_t depth;
   uint32_t counts[5][2];
+  /* PerRead[4][]PerReadFeatures (row.go:48-52); only used when perReadNeeded */
+  orc_feat* pr[4];
+  uint32_t npr[4], cpr[4];
 } payload;
 
 typedef struct {
@@ -503,6 +512,10 @@ typedef struct {
   int64_t cap, n;
   int32_t *out_ref, *out_pos;
   uint32_t* out_vals;
+  /* per-read lists, in row order: list b of row i = feat[off[4i+b] .. off[4i+b+1]) */
+  uint64_t* out_off;
+  orc_feat* out_feat;
+  int64_t feat_cap, n_feat;
 } rowsink;
 
 typedef struct {
@@ -528,6 +541,7 @@ typedef struct {
   read_snp orphan;
   rowsink* sink;
   errbuf* err;
+  int per_read; /* pCtx.perReadNeeded (pileup.go:888) */
 } job;
 
 static int sink_append(job* j, int32_t ref, int32_t pos, const payload* p) {
@@ -544,6 +558,16 @@ static int sink_append(job* j, int32_t ref, int32_t pos, const payload* p) {
     }
   } else {
     memset(v, 0, sizeof(uint32_t) * BP_ROW_U32);
+  }
+  if (s->out_off) {
+    for (int b = 0; b < 4; b++) {
+      s->out_off[4 * s->n + b] = (uint64_t)s->n_feat;
+      uint32_t m = p ? p->npr[b] : 0;
+      if (s->n_feat + m > s->feat_cap) FAIL(j->err, "oracle: feature capacity %lld exceeded", (long long)s->feat_cap);
+      if (m) memcpy(s->out_feat + s->n_feat, p->pr[b], sizeof(orc_feat) * m);
+      s->n_feat += m;
+    }
+    s->out_off[4 * s->n + 4] = (uint64_t)s->n_feat;
   }
   s->n++;
   return 0;
@@ -728,12 +752,43 @@ static inline void add_base(job* j, int32_t circ, int32_t pos_in_read, int32_t i
   if (qual[pos_in_read] >= (uint8_t)j->o->min_base_qual || base == 4) row->counts[base][is_minus]++;
 }
 
-/* addUnstitchedSegment (pileup.go:254-267), counts-only branch */
+/* appendBase (pileup.go:235-250) */
+static inline void append_base(job* j, int32_t circ, int32_t pos_in_read, int32_t is_minus,
+                               const uint8_t* seq, const uint8_t* qual, uint32_t qual_len,
+                               uint8_t strand_byte) {
+  payload* row = &j->ring[circ];
+  row->depth++;
+  uint8_t base = kSeq8ToEnum[seq[pos_in_read]];
+  if (base == 4) {
+    row->counts[base][is_minus]++;
+  } else if (qual[pos_in_read] >= (uint8_t)j->o->min_base_qual) {
+    row->counts[base][is_minus]++;
+    if (row->npr[base] == row->cpr[base]) {
+      row->cpr[base] = row->cpr[base] ? 2 * row->cpr[base] : 8;
+      row->pr[base] = (orc_feat*)realloc(row->pr[base], sizeof(orc_feat) * row->cpr[base]);
+    }
+    orc_feat* f = &row->pr[base][row->npr[base]++];
+    f->dist5p = (uint16_t)pos_in_read;
+    f->fraglen = (uint16_t)qual_len;
+    f->qual = qual[pos_in_read];
+    f->strand = strand_byte;
+  }
+}
+
+/* addUnstitchedSegment (pileup.go:254-267) */
 static void add_unstitched(job* j, const read_snp* rd, int32_t is_minus, const aligned_pos* ab,
                            uint32_t n) {
   int32_t mask = j->n_circ - 1;
-  for (uint32_t k = 0; k < n; k++)
-    add_base(j, ab[k].pos_in_ref & mask, ab[k].pos_in_read, is_minus, rd->seq8, rd->qual);
+  if (!j->per_read) {
+    for (uint32_t k = 0; k < n; k++)
+      add_base(j, ab[k].pos_in_ref & mask, ab[k].pos_in_read, is_minus, rd->seq8, rd->qual);
+  } else {
+    const bp_record_batch* r = j->recs;
+    uint8_t sb = (uint8_t)orc_get_strand(r->ref_id[rd->rec], r->mate_ref_id[rd->rec], r->flags[rd->rec]);
+    for (uint32_t k = 0; k < n; k++)
+      append_base(j, ab[k].pos_in_ref & mask, ab[k].pos_in_read, is_minus, rd->seq8, rd->qual,
+                  r->l_seq[rd->rec], sb);
+  }
 }
 
 /* addReadPair (pileup.go:366-465) */
@@ -772,6 +827,8 @@ static int add_read_pair(job* j, read_snp* reads, int n_read, int32_t is_minus) 
       int32_t r0 = a0[i0].pos_in_read, r1 = a1[i1].pos_in_read;
       uint8_t c0 = s0[r0], c1 = s1[r1];
       if (c0 == c1) {
+        if (j->per_read) /* a Go panic (pileup.go:422-425) */
+          FAIL(j->err, "stitched per-read features not yet supported");
         uint8_t base = kSeq8ToEnum[c0];
         uint8_t qa = q0[r0], qb = q1[r1];
         if (qa >= NQUAL || qb >= NQUAL)
@@ -784,9 +841,11 @@ static int add_read_pair(job* j, read_snp* reads, int n_read, int32_t is_minus) 
       i0++;
       i1++;
     } else if (p0 < p1) {
+      if (j->per_read) FAIL(j->err, "stitched per-read features not yet supported"); /* pileup.go:435 */
       add_base(j, p0 & mask, a0[i0].pos_in_read, is_minus, s0, q0);
       i0++;
     } else {
+      if (j->per_read) FAIL(j->err, "stitched per-read features not yet supported"); /* pileup.go:442 */
       add_base(j, p1 & mask, a1[i1].pos_in_read, is_minus, s1, q1);
       i1++;
     }
@@ -920,7 +979,9 @@ static int flush_to_internal(job* j, int32_t write_end) {
         if (sink_append(j, j->ref_id, pos, NULL)) return -1;
       } else {
         if (sink_append(j, j->ref_id, pos, row)) return -1;
-        memset(row, 0, sizeof(*row));
+        row->depth = 0;
+        memset(row->counts, 0, sizeof(row->counts));
+        memset(row->npr, 0, sizeof(row->npr));
       }
     }
   }
@@ -1128,10 +1189,11 @@ static void read_snp_free(read_snp* r) {
  * Rows are appended in job order, like the converters read tmpFiles in order
  * (output.go:136).  Returns 0, or -1 with err filled.
  */
-int orc_pileup(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const uint64_t* bed_off,
-               const int32_t* bed_ep, const bp_record_batch* recs, int32_t n_shards,
-               const orc_shard* shards, int32_t parallelism, int64_t cap_rows, int32_t* out_ref,
-               int32_t* out_pos, uint32_t* out_vals, int64_t* n_rows, char* err, int32_t errlen) {
+static int pileup_impl(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const uint64_t* bed_off,
+                       const int32_t* bed_ep, const bp_record_batch* recs, int32_t n_shards,
+                       const orc_shard* shards, int32_t parallelism, int64_t cap_rows, int32_t* out_ref,
+                       int32_t* out_pos, uint32_t* out_vals, int64_t* n_rows, uint64_t* out_off,
+                       orc_feat* out_feat, int64_t feat_cap, int64_t* n_feat, char* err, int32_t errlen) {
   errbuf e = {err, errlen, 0};
   if (errlen > 0) err[0] = 0;
   *n_rows = 0;
@@ -1149,7 +1211,7 @@ int orc_pileup(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const ui
     uint64_t n = bed_off[i + 1] - bed_off[i];
     if (n) bed_set_copy(&full, i, bed_ep + bed_off[i], (uint32_t)n);
   }
-  rowsink sink = {cap_rows, 0, out_ref, out_pos, out_vals};
+  rowsink sink = {cap_rows, 0, out_ref, out_pos, out_vals, out_off, out_feat, feat_cap, 0};
   if (parallelism <= 0 || parallelism > n_shards) parallelism = n_shards;
 
   int32_t n_circ = orc_next_exp2(o->max_read_span);
@@ -1164,6 +1226,7 @@ int orc_pileup(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const ui
     j.recs = recs;
     j.sink = &sink;
     j.err = &e;
+    j.per_read = out_off != NULL;
     j.ref_id = -1;
     j.prev_limit_id = -1;
     j.n_circ = n_circ;
@@ -1206,6 +1269,8 @@ int orc_pileup(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const ui
       j.prev_limit_pos = (int64_t)sh->end + sh->padding;
     }
     if (rc == 0) rc = finish_ref(&j, n_ref);
+    for (int32_t c = 0; c < n_circ; c++)
+      for (int b = 0; b < 4; b++) free(j.ring[c].pr[b]);
     free(j.ring);
     free(j.ab[0]);
     free(j.ab[1]);
@@ -1217,7 +1282,32 @@ int orc_pileup(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const ui
   }
   bed_free(&full);
   *n_rows = sink.n;
+  if (n_feat) *n_feat = sink.n_feat;
   return rc;
+}
+
+int orc_pileup(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const uint64_t* bed_off,
+               const int32_t* bed_ep, const bp_record_batch* recs, int32_t n_shards,
+               const orc_shard* shards, int32_t parallelism, int64_t cap_rows, int32_t* out_ref,
+               int32_t* out_pos, uint32_t* out_vals, int64_t* n_rows, char* err, int32_t errlen) {
+  return pileup_impl(o, n_ref, ref_len, bed_off, bed_ep, recs, n_shards, shards, parallelism, cap_rows,
+                     out_ref, out_pos, out_vals, n_rows, NULL, NULL, 0, NULL, err, errlen);
+}
+
+/* Same run with pCtx.perReadNeeded set (pileup.go:888): additionally returns the ordered
+ * per-read feature lists of every row (appendBase, pileup.go:235-250).  out_off has
+ * 4*cap_rows+1 entries; out_feat has feat_cap 6-byte entries {u16 dist5p, u16 fraglen, u8 qual,
+ * u8 strand}. */
+int orc_pileup_per_read(const bp_opts* o, int32_t n_ref, const int32_t* ref_len, const uint64_t* bed_off,
+                        const int32_t* bed_ep, const bp_record_batch* recs, int32_t n_shards,
+                        const orc_shard* shards, int32_t parallelism, int64_t cap_rows, int32_t* out_ref,
+                        int32_t* out_pos, uint32_t* out_vals, int64_t* n_rows, uint64_t* out_off,
+                        void* out_feat, int64_t feat_cap, int64_t* n_feat, char* err, int32_t errlen) {
+  if (!out_off || !out_feat) return -1;
+  out_off[0] = 0;
+  return pileup_impl(o, n_ref, ref_len, bed_off, bed_ep, recs, n_shards, shards, parallelism, cap_rows,
+                     out_ref, out_pos, out_vals, n_rows, out_off, (orc_feat*)out_feat, feat_cap, n_feat, err,
+                     errlen);
 }
 
 /* Exposed for BED KATs (interval/bedunion_internal_test.go): Subset of a one-reference

@@ -139,6 +139,10 @@ class OracleError(RuntimeError):
     pass
 
 
+# PerReadFeatures (pileup/snp/row.go:22-31) as the oracle and the C ABI lay them out
+FEAT_DTYPE = np.dtype([("dist5p", "<u2"), ("fraglen", "<u2"), ("qual", "u1"), ("strand", "u1")])
+
+
 def pileup(opts, ref_len, bed, batch, shards=None, n_shards=None, parallelism=1):
     """Run the oracle.  bed = {ref_id: [[s,e],...]}.  shards default to the -bed mode
     100-kb position shards with Padding = max_read_span (pileup.go:1073-1084).
@@ -165,3 +169,37 @@ def pileup(opts, ref_len, bed, batch, shards=None, n_shards=None, parallelism=1)
         raise OracleError(err.value.decode())
     n = n_rows.value
     return out_ref[:n], out_pos[:n], out_vals[:n]
+
+
+def pileup_per_read(opts, ref_len, bed, batch, shards=None, n_shards=None, parallelism=1, feat_cap=None):
+    """The oracle with perReadNeeded set: (ref, pos, vals, off[4P+1], feats[FEAT_DTYPE])."""
+    lib = load()
+    rl = np.ascontiguousarray(ref_len, np.int32)
+    n_ref = len(rl)
+    if shards is None:
+        shards, n_shards = position_shards(rl, 100000, opts.max_read_span)
+    off, ep = bed_arrays(n_ref, bed)
+    cap = n_bed_positions(bed) + 1
+    if feat_cap is None:
+        feat_cap = int(batch.l_seq.astype(np.int64).sum()) + 1
+    out_ref = np.zeros(cap, np.int32)
+    out_pos = np.zeros(cap, np.int32)
+    out_vals = np.zeros((cap, BP_ROW_U32), np.uint32)
+    out_off = np.zeros(4 * cap + 1, np.uint64)
+    out_feat = np.zeros(feat_cap, FEAT_DTYPE)
+    assert FEAT_DTYPE.itemsize == 6
+    n_rows, n_feat = C.c_int64(0), C.c_int64(0)
+    err = C.create_string_buffer(512)
+    cb = batch.as_c()
+    i32p, u32p, u64p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    lib.orc_pileup_per_read.restype = C.c_int
+    rc = lib.orc_pileup_per_read(C.byref(opts), n_ref, rl.ctypes.data_as(i32p), off.ctypes.data_as(u64p),
+                                 ep.ctypes.data_as(i32p), C.byref(cb), C.c_int32(n_shards), shards,
+                                 C.c_int32(parallelism), C.c_int64(cap), out_ref.ctypes.data_as(i32p),
+                                 out_pos.ctypes.data_as(i32p), out_vals.ctypes.data_as(u32p), C.byref(n_rows),
+                                 out_off.ctypes.data_as(u64p), out_feat.ctypes.data_as(C.c_void_p),
+                                 C.c_int64(feat_cap), C.byref(n_feat), err, C.c_int32(512))
+    if rc != 0:
+        raise OracleError(err.value.decode())
+    n = n_rows.value
+    return out_ref[:n], out_pos[:n], out_vals[:n], out_off[:4 * n + 1], out_feat[:n_feat.value]

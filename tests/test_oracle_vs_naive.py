@@ -208,3 +208,33 @@ def test_oracle_errors():
         O.pileup(O.make_opts(clip=250), [1000], bed, R.from_records([long_read]))
     with pytest.raises(O.OracleError, match="max-read-len"):
         O.pileup(O.make_opts(max_read_len=600), [1000], bed, R.from_records([long_read]))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_oracle_per_read_lists_match_naive(seed):
+    """appendBase (pileup.go:235-250): ordered per-read feature lists, oracle vs naive."""
+    rng = random.Random(500 + seed)
+    ref_len = 2500
+    batch = R.from_records(random_records(rng, 120, ref_len=ref_len))
+    bed = random_bed(rng, ref_len, dense=True)
+    opts = O.make_opts(max_read_len=100, max_read_span=120, min_base_qual=20, clip=seed - 1, mapq=0)
+    ref, pos, vals, off, feats = O.pileup_per_read(opts, [ref_len], bed, batch)
+    # counts are unchanged by perReadNeeded
+    r2, p2, v2 = O.pileup(opts, [ref_len], bed, batch)
+    assert (pos == p2).all() and (vals == v2).all()
+    want = {}
+    N.pileup(opts, bed, batch, per_read=want)
+    n_lists = 0
+    for i in range(len(pos)):
+        lists = want.get((int(ref[i]), int(pos[i])), [[], [], [], []])
+        for b in range(4):
+            got = feats[int(off[4 * i + b]):int(off[4 * i + b + 1])]
+            assert [tuple(int(x) for x in f) for f in got] == lists[b], (int(pos[i]), b)
+            # list length = passing non-X count (pileup.go:241-248)
+            assert len(got) == int(vals[i, 1 + 2 * b]) + int(vals[i, 2 + 2 * b])
+            n_lists += len(got) > 0
+    assert n_lists > 500
+    # stitched per-read features: the reference panics at the first merged pair
+    sopts = O.make_opts(max_read_len=100, max_read_span=120, stitch=1, mapq=0)
+    with pytest.raises(O.OracleError, match="stitched per-read features not yet supported"):
+        O.pileup_per_read(sopts, [ref_len], bed, batch)

@@ -64,6 +64,7 @@ EXPORTS = [
     "bp_init", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute",
     "bp_num_rows", "bp_rows", "bp_rows_device", "bp_column_sums", "bp_get_timing",
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
+    "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
 ]
 
 HOST_EXPORTS = [
@@ -142,6 +143,14 @@ def load():
     lib.bp_last_error.restype = C.c_char_p
     lib.bp_destroy.argtypes = [H]
     lib.bp_destroy.restype = None
+    lib.bp_per_read_build.argtypes = [H]
+    lib.bp_per_read_build.restype = C.c_int
+    lib.bp_per_read_total.argtypes = [H]
+    lib.bp_per_read_total.restype = C.c_int64
+    lib.bp_per_read_offsets.argtypes = [H, C.c_int64, C.c_int64, C.POINTER(C.c_uint64)]
+    lib.bp_per_read_offsets.restype = C.c_int
+    lib.bp_per_read_features.argtypes = [H, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.bp_per_read_features.restype = C.c_int
     # include/bio_pileup_host.h
     E = [C.c_char_p, C.c_size_t]
     lib.bio_pileup_default_opts.argtypes = [C.POINTER(bio_pileup_opts)]

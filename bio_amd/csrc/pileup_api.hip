@@ -31,6 +31,11 @@ void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s)
 void launch_pileup(const KernelParams& P, hipStream_t s);
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s);
 int window_size();
+void launch_list_lengths(const uint32_t* rows, int64_t n_rows, unsigned long long* lens, hipStream_t s);
+void launch_tile_scan(unsigned long long* a, int64_t n, unsigned long long* tile_sum, hipStream_t s);
+void launch_tile_add(unsigned long long* a, int64_t n, const unsigned long long* tile_base, hipStream_t s);
+void launch_per_read(const KernelParams& P, const int32_t* iv_ref, int32_t n_iv, int64_t n_rows,
+                     const unsigned long long* off, PerRead* out, int32_t* bad_row, hipStream_t s);
 }  // namespace bp
 
 using namespace bp;
@@ -103,7 +108,9 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr, d_dbg, d_ref_first;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_feat;
+  bool per_read_valid = false;
+  uint64_t n_feat = 0;
   Staging stage[2];
   int cur_stage = 0;
   bp_timing timing{};
@@ -644,6 +651,34 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
   return BP_OK;
 }
 
+// Kernel arguments for the handle's resident job.
+static void fill_params(bp_handle* h, KernelParams& P) {
+  P.cores = (const ReadCore*)h->d_cores.p;
+  P.blob = (const uint8_t*)h->d_blob.p;
+  P.mate = h->o.stitch ? (const MateRef*)h->d_mate.p : nullptr;
+  P.windows = (const Window*)h->d_windows.p;
+  P.win_r0 = (const int32_t*)h->d_r0.p;
+  P.win_r1 = (const int32_t*)h->d_r1.p;
+  P.ref_first = (const int64_t*)h->d_ref_first.p;
+  P.iv_start = (const int32_t*)h->d_iv_start.p;
+  P.iv_end = (const int32_t*)h->d_iv_end.p;
+  P.iv_row = (const int64_t*)h->d_iv_row.p;
+  P.rows = (uint32_t*)h->d_rows.p;
+  P.err = (DeviceError*)h->d_err.p;
+  P.qthr = (const uint8_t*)h->d_qthr.p;
+  P.dbg = nullptr;
+  P.n_reads = h->n_reads;
+  P.n_windows = (int32_t)h->windows.size();
+  P.max_span = h->max_span;
+  P.clip = h->o.clip;
+  P.flag_exclude = h->o.flag_exclude;
+  P.mapq = h->o.mapq;
+  P.min_base_qual = h->o.min_base_qual;
+  P.stitch = h->o.stitch;
+  P.ignore_strand = h->o.ignore_strand;
+  P.strand_req = h->o.strand_req;
+}
+
 int bp_compute(bp_handle* h) {
   if (!h) return fail(h, BP_EINVAL, "bp_compute: null handle");
   HIP_TRY(h, hipSetDevice(h->device));
@@ -670,35 +705,12 @@ int bp_compute(bp_handle* h) {
   DeviceError init{0x7fffffff, ERR_NONE};
   HIP_TRY(h, hipMemcpyAsync(h->d_err.p, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
   KernelParams P{};
-  P.cores = (const ReadCore*)h->d_cores.p;
-  P.blob = (const uint8_t*)h->d_blob.p;
-  P.mate = h->o.stitch ? (const MateRef*)h->d_mate.p : nullptr;
-  P.windows = (const Window*)h->d_windows.p;
-  P.win_r0 = (const int32_t*)h->d_r0.p;
-  P.win_r1 = (const int32_t*)h->d_r1.p;
-  P.ref_first = (const int64_t*)h->d_ref_first.p;
-  P.iv_start = (const int32_t*)h->d_iv_start.p;
-  P.iv_end = (const int32_t*)h->d_iv_end.p;
-  P.iv_row = (const int64_t*)h->d_iv_row.p;
-  P.rows = (uint32_t*)h->d_rows.p;
-  P.err = (DeviceError*)h->d_err.p;
-  P.qthr = (const uint8_t*)h->d_qthr.p;
-  P.dbg = nullptr;
+  fill_params(h, P);
 #ifdef BP_STAMPS
   if (int rc = ensure(h, h->d_dbg, h->windows.size() * 8 * (8 * 8 + 8 * 4) + 256, 0)) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_dbg.p, 0, h->windows.size() * 8 * (8 * 8 + 8 * 4), h->stream));
   P.dbg = (unsigned long long*)h->d_dbg.p;
 #endif
-  P.n_reads = h->n_reads;
-  P.n_windows = (int32_t)h->windows.size();
-  P.max_span = h->max_span;
-  P.clip = h->o.clip;
-  P.flag_exclude = h->o.flag_exclude;
-  P.mapq = h->o.mapq;
-  P.min_base_qual = h->o.min_base_qual;
-  P.stitch = h->o.stitch;
-  P.ignore_strand = h->o.ignore_strand;
-  P.strand_req = h->o.strand_req;
   HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
   launch_plan(P, (int32_t*)h->d_r0.p, (int32_t*)h->d_r1.p, h->stream);
   HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
@@ -719,6 +731,7 @@ int bp_compute(bp_handle* h) {
                 "qualPassTable.lookup2: base quality >= 96 in a stitched overlap (record %d); the "
                 "reference panics with index out of range (qual.go:26,79-81)", got.read);
   h->rows_valid = true;
+  h->per_read_valid = false;
   return BP_OK;
 }
 
@@ -784,6 +797,83 @@ int bp_column_sums(bp_handle* h, uint64_t sums[BP_ROW_U32]) {
   return BP_OK;
 }
 
+int bp_per_read_build(bp_handle* h) {
+  if (!h) return fail(h, BP_EINVAL, "bp_per_read_build: null handle");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_per_read_build: no computed rows (call bp_finish)");
+  if (h->o.stitch)  // the reference panics at the first merged pair (pileup.go:422-443)
+    return fail(h, BP_EINVAL, "stitched per-read features not yet supported");
+  if (h->per_read_valid) return BP_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int64_t n = 4 * h->n_rows;
+  const int64_t n_tiles = (n + 1023) / 1024;
+  if (int rc = ensure(h, h->d_pr_off, (size_t)(n + 1) * 8 + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_pr_tiles, (size_t)n_tiles * 8 + 256, 0)) return rc;
+  unsigned long long* off = (unsigned long long*)h->d_pr_off.p;
+  launch_list_lengths((const uint32_t*)h->d_rows.p, h->n_rows, off, h->stream);
+  launch_tile_scan(off, n, (unsigned long long*)h->d_pr_tiles.p, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<unsigned long long> tiles((size_t)n_tiles);
+  if (n_tiles)
+    HIP_TRY(h, hipMemcpyAsync(tiles.data(), h->d_pr_tiles.p, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  unsigned long long run = 0;
+  for (auto& t : tiles) {
+    const unsigned long long v = t;
+    t = run;
+    run += v;
+  }
+  h->n_feat = run;
+  if (n_tiles)
+    HIP_TRY(h, hipMemcpyAsync(h->d_pr_tiles.p, tiles.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, h->stream));
+  launch_tile_add(off, n, (const unsigned long long*)h->d_pr_tiles.p, h->stream);
+  HIP_TRY(h, hipMemcpyAsync(off + n, &run, 8, hipMemcpyHostToDevice, h->stream));
+  if (int rc = ensure(h, h->d_pr_feat, (size_t)run * sizeof(PerRead) + 256, 0)) return rc;
+  const size_t n_iv = h->iv_ref.size();
+  if (int rc = ensure(h, h->d_iv_ref, n_iv * 4 + 256, 0)) return rc;
+  if (n_iv) HIP_TRY(h, hipMemcpyAsync(h->d_iv_ref.p, h->iv_ref.data(), n_iv * 4, hipMemcpyHostToDevice, h->stream));
+  if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
+  const int32_t none = 0x7fffffff;
+  HIP_TRY(h, hipMemcpyAsync(h->d_err.p, &none, 4, hipMemcpyHostToDevice, h->stream));
+  KernelParams P{};
+  fill_params(h, P);
+  launch_per_read(P, (const int32_t*)h->d_iv_ref.p, (int32_t)n_iv, h->n_rows, off, (PerRead*)h->d_pr_feat.p,
+                  (int32_t*)h->d_err.p, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  int32_t bad = 0;
+  HIP_TRY(h, hipMemcpyAsync(&bad, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (bad != none)
+    return fail(h, BP_EDEVICE, "bp_per_read_build: list lengths of row %d disagree with its counts", bad);
+  h->per_read_valid = true;
+  return BP_OK;
+}
+
+int64_t bp_per_read_total(const bp_handle* h) { return h && h->per_read_valid ? (int64_t)h->n_feat : -1; }
+
+int bp_per_read_offsets(bp_handle* h, int64_t first_row, int64_t n_rows, uint64_t* off) {
+  if (!h || !off) return fail(h, BP_EINVAL, "bp_per_read_offsets: null argument");
+  if (!h->per_read_valid) return fail(h, BP_EINVAL, "bp_per_read_offsets: call bp_per_read_build first");
+  if (first_row < 0 || n_rows < 0 || first_row + n_rows > h->n_rows)
+    return fail(h, BP_EINVAL, "bp_per_read_offsets: rows [%lld,%lld) of %lld", (long long)first_row,
+                (long long)(first_row + n_rows), (long long)h->n_rows);
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy(off, (const uint64_t*)h->d_pr_off.p + 4 * first_row, (size_t)(4 * n_rows + 1) * 8,
+                       hipMemcpyDeviceToHost));
+  return BP_OK;
+}
+
+int bp_per_read_features(bp_handle* h, uint64_t first, uint64_t n, bp_per_read* out) {
+  if (!h || (!out && n)) return fail(h, BP_EINVAL, "bp_per_read_features: null argument");
+  if (!h->per_read_valid) return fail(h, BP_EINVAL, "bp_per_read_features: call bp_per_read_build first");
+  if (first + n > h->n_feat)
+    return fail(h, BP_EINVAL, "bp_per_read_features: entries [%llu,%llu) of %llu", (unsigned long long)first,
+                (unsigned long long)(first + n), (unsigned long long)h->n_feat);
+  if (n == 0) return BP_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy(out, (const PerRead*)h->d_pr_feat.p + first, (size_t)n * sizeof(PerRead), hipMemcpyDeviceToHost));
+  return BP_OK;
+}
+
 int bp_get_timing(const bp_handle* h, bp_timing* out) {
   if (!h || !out) return BP_EINVAL;
   *out = h->timing;
@@ -808,7 +898,7 @@ void bp_destroy(bp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+  for (DevBuf* b : {&h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {

@@ -32,7 +32,8 @@ enum : uint8_t {
 // Payload ("blob") of a record, 8-byte aligned:
 //   uint32 cigar[n_cigar rounded up to even]
 //   uint8  qual[8*U]      U = ceil(l_seq/8); pad bytes 0
-//   uint8  seq4[4*U]      BAM packed 4-bit bases; pad nibbles 0
+//   uint8  seq4[4*U]      packed 4-bit bases (BAM codes), first base of a byte in the LOW
+//                         nibble (BAM has it in the high one); pad nibbles 0
 //   pad to 8 bytes
 inline uint32_t blob_units(uint32_t l_seq) { return (l_seq + 7) >> 3; }
 inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq) {
@@ -85,5 +86,12 @@ struct KernelParams {
   // options (bp_opts)
   int32_t clip, flag_exclude, mapq, min_base_qual, stitch, ignore_strand, strand_req;
 };
+
+// One entry of a per-read feature list = PerReadFeatures (pileup/snp/row.go:22-31), 6 bytes.
+struct PerRead {
+  uint16_t dist5p, fraglen;
+  uint8_t qual, strand;
+};
+static_assert(sizeof(PerRead) == 6, "PerRead must be 6 bytes");
 
 }  // namespace bp

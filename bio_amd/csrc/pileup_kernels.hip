@@ -935,6 +935,142 @@ __global__ void column_sums_kernel(const uint32_t* rows, int64_t n_rows, unsigne
   if (threadIdx.x < 11) atomicAdd(&sums[threadIdx.x], s[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------- per-read feature lists
+// appendBase (pileup.go:235-250): with a per-read column set every passing non-X base also
+// appends {index in read, read length, qual, GetStrand} to PerRead[base] of its position, in
+// read-arrival order.  The list lengths are the counts the pileup kernel already produced
+// (Counts[b][0] + Counts[b][1]), so the lists are laid out by an exclusive scan and filled
+// by a gather: one thread per BED position walks the records that can cover it in index
+// order (= arrival order), which gives the reference's order with no atomics and no sort.
+// This path serves targeted panels and small regions; it is not tuned.
+
+// lens[4r + b] = length of list b of row r
+__global__ void list_lengths_kernel(const uint32_t* rows, int64_t n_rows, unsigned long long* lens) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * n_rows) return;
+  const uint32_t* v = rows + (i >> 2) * 11;
+  const int b = (int)(i & 3);
+  lens[i] = (unsigned long long)v[1 + 2 * b] + v[2 + 2 * b];
+}
+
+// In-place exclusive scan of 1024-element tiles; tile totals go to tile_sum.
+__global__ __launch_bounds__(256) void tile_scan_kernel(unsigned long long* a, int64_t n,
+                                                        unsigned long long* tile_sum) {
+  __shared__ unsigned long long sh[256];
+  const int64_t base = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+  unsigned long long v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    v[k] = base + k < n ? a[base + k] : 0;
+    s += v[k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned long long t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned long long run = sh[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k < n) a[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 255) tile_sum[blockIdx.x] = sh[255];
+}
+
+__global__ void tile_add_kernel(unsigned long long* a, int64_t n, const unsigned long long* tile_base) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += tile_base[i >> 10];
+}
+
+__global__ void per_read_kernel(KernelParams P, const int32_t* iv_ref, int32_t n_iv, int64_t n_rows,
+                                const unsigned long long* off, PerRead* out, int32_t* bad_row) {
+  const int64_t R = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (R >= n_rows) return;
+  // row -> (reference, position)
+  int32_t a = 0, b = n_iv;  // last interval with iv_row <= R
+  while (b - a > 1) {
+    const int32_t m = (a + b) >> 1;
+    if (P.iv_row[m] <= R) a = m; else b = m;
+  }
+  const int32_t ref = iv_ref[a];
+  const int32_t p = P.iv_start[a] + (int32_t)(R - P.iv_row[a]);
+  // records of the reference that can cover p: pos in (p - max_span, p]
+  int64_t lo = P.ref_first[ref];
+  const int64_t hi = P.ref_first[ref + 1];
+  {
+    int64_t x = lo, y = hi;
+    const int64_t want = (int64_t)p - P.max_span + 1;
+    while (x < y) {
+      const int64_t m = (x + y) >> 1;
+      if ((int64_t)P.cores[m].pos < want) x = m + 1; else y = m;
+    }
+    lo = x;
+  }
+  uint32_t cnt[4] = {0, 0, 0, 0};
+  for (int64_t i = lo; i < hi; i++) {
+    const ReadCore c = P.cores[i];
+    if (c.pos > p) break;
+    if ((int64_t)c.pos + c.span <= (int64_t)p) continue;
+    // read-level filters (pileup.go:691, :717-729)
+    if (((uint32_t)P.flag_exclude & c.flags) != 0 || (int32_t)c.mapq < P.mapq || c.n_cigar == 0) continue;
+    const int strand = strand_of((c.aux & AUX_MATE_SAME) != 0, c.flags);
+    if (P.strand_req != 0) {
+      if (strand != P.strand_req) continue;
+    } else if (strand == 0 && !P.ignore_strand) {
+      continue;
+    }
+    const int32_t mi = read_index_at(c, P.blob, p);
+    if (mi < 0) continue;
+    const uint8_t* rb = P.blob + (uint64_t)c.blob * 8;
+    const uint32_t cigb = ((c.n_cigar + 1u) & ~1u) * 4;
+    const uint32_t byte = rb[cigb + 8 * (((uint32_t)c.l_seq + 7) >> 3) + (mi >> 1)];
+    const uint32_t nib = (mi & 1) ? (byte >> 4) : (byte & 15u);
+    // Seq8ToEnumTable (pileup/common.go:66)
+    const int e = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : 4;
+    if (e == 4) continue;  // X is counted, never listed (pileup.go:239-240)
+    uint32_t q = rb[cigb + mi];
+    if (P.clip > 0) q = clipped_qual(q, mi, (int32_t)c.l_seq, P.clip);
+    if (q < (uint32_t)P.min_base_qual) continue;
+    const unsigned long long o = off[4 * R + e] + cnt[e];
+    if (o < off[4 * R + e + 1]) {
+      PerRead f;
+      f.dist5p = (uint16_t)mi;
+      f.fraglen = c.l_seq;
+      f.qual = (uint8_t)q;
+      f.strand = (uint8_t)strand;
+      out[o] = f;
+    }
+    cnt[e]++;
+  }
+  // the lists must be exactly as long as the counts said
+  for (int e = 0; e < 4; e++)
+    if (off[4 * R + e] + cnt[e] != off[4 * R + e + 1]) atomicMin(bad_row, (int32_t)(R > 0x7ffffffe ? 0x7ffffffe : R));
+}
+
+void launch_list_lengths(const uint32_t* rows, int64_t n_rows, unsigned long long* lens, hipStream_t s) {
+  if (n_rows == 0) return;
+  const int64_t n = 4 * n_rows;
+  hipLaunchKernelGGL(list_lengths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, n_rows, lens);
+}
+void launch_tile_scan(unsigned long long* a, int64_t n, unsigned long long* tile_sum, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, a, n, tile_sum);
+}
+void launch_tile_add(unsigned long long* a, int64_t n, const unsigned long long* tile_base, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(tile_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, tile_base);
+}
+void launch_per_read(const KernelParams& P, const int32_t* iv_ref, int32_t n_iv, int64_t n_rows,
+                     const unsigned long long* off, PerRead* out, int32_t* bad_row, hipStream_t s) {
+  if (n_rows == 0) return;
+  hipLaunchKernelGGL(per_read_kernel, dim3((unsigned)((n_rows + 127) / 128)), dim3(128), 0, s, P, iv_ref, n_iv,
+                     n_rows, off, out, bad_row);
+}
+
 // ---- launch wrappers (called from pileup_api.hip)
 void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s) {
   if (P.n_windows == 0) return;

@@ -38,6 +38,10 @@ DEFAULT_OPTS = Opts()
 FORMATS = ("basestrand-rio", "basestrand-tsv", "basestrand-tsv-bgz", "tsv", "tsv-bgz")
 
 
+# bp_per_read = PerReadFeatures (pileup/snp/row.go:22-31)
+PER_READ_DTYPE = np.dtype([("dist5p", "<u2"), ("fraglen", "<u2"), ("qual", "u1"), ("strand", "u1")])
+
+
 class PileupError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(msg)
@@ -118,6 +122,19 @@ class PileupJob:
                                      pos.ctypes.data_as(i32p),
                                      vals.ctypes.data_as(C.POINTER(C.c_uint32))))
         return ref, pos, vals
+
+    def per_read(self, first=0, n=None):
+        """Per-read feature lists of rows [first, first+n) (bp_per_read_*): (off[4n+1] relative
+        to the returned array, feats[PER_READ_DTYPE])."""
+        if n is None:
+            n = self.num_rows - first
+        self._check(self.lib.bp_per_read_build(self.h))
+        off = np.zeros(4 * n + 1, np.uint64)
+        self._check(self.lib.bp_per_read_offsets(self.h, first, n, off.ctypes.data_as(C.POINTER(C.c_uint64))))
+        lo, hi = int(off[0]), int(off[-1])
+        feats = np.zeros(hi - lo, PER_READ_DTYPE)
+        self._check(self.lib.bp_per_read_features(self.h, lo, hi - lo, feats.ctypes.data_as(C.c_void_p)))
+        return off - off[0], feats
 
     def column_sums(self):
         s = (C.c_uint64 * _abi.BP_ROW_U32)()

@@ -152,6 +152,28 @@ int bp_rows_device(bp_handle* h, const uint32_t** dptr);
  * Size-independent parity check: sums[0] = total depth. */
 int bp_column_sums(bp_handle* h, uint64_t sums[BP_ROW_U32]);
 
+/* Per-read feature lists: what appendBase adds to PileupPayload.PerRead when a per-read
+ * column set is requested (pCtx.perReadNeeded, pileup.go:235-250, :888; PerReadFeatures
+ * row.go:22-31).  List b (A,C,G,T = 0..3) of a row holds one entry per passing non-X base of
+ * that position, in read-arrival order; its length is Counts[b][0]+Counts[b][1]. */
+typedef struct bp_per_read {
+  uint16_t dist5p;  /* index of the base in its read (pileup.go:244) */
+  uint16_t fraglen; /* len(Qual) of the read (pileup.go:245) */
+  uint8_t qual;     /* after clipQuals */
+  uint8_t strand;   /* pileup.GetStrand of the read: 0 none, 1 fwd, 2 rev */
+} bp_per_read;
+
+/* Builds the lists of the computed rows on the device (after bp_finish / bp_compute).  With
+ * opts.stitch it fails with the reference's panic text (pileup.go:422-443). */
+int bp_per_read_build(bp_handle* h);
+/* Total number of entries over all rows, or -1 before bp_per_read_build. */
+int64_t bp_per_read_total(const bp_handle* h);
+/* off[4*i + b] .. off[4*i + b + 1] = entries of list b of row first_row+i; writes
+ * 4*n_rows + 1 absolute entry indices. */
+int bp_per_read_offsets(bp_handle* h, int64_t first_row, int64_t n_rows, uint64_t* off);
+/* Copies entries [first, first+n) to host. */
+int bp_per_read_features(bp_handle* h, uint64_t first, uint64_t n, bp_per_read* out);
+
 int bp_get_timing(const bp_handle* h, bp_timing* out);
 
 /* Algorithmic bytes of the resident job per SURVEY.md section 8(d):

@@ -260,3 +260,45 @@ def test_logical_partitions_on_one_device(stitch):
                  for rg in P.plan_partitions(bed, world)]
         got = tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
         assert_same(got, want, f"{world} partitions stitch={stitch}")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_per_read_lists_vs_oracle(seed):
+    """appendBase (pileup.go:235-250): ordered per-read feature lists from the device against
+    the oracle's, entry for entry."""
+    rng = random.Random(600 + seed)
+    ref_lens = [4000, 2500]
+    recs = []
+    for r, L in enumerate(ref_lens):
+        part = random_records(rng, 300, ref_len=L, read_len=60)
+        for x in part:
+            x["mate_ref_id"] = r if x["mate_ref_id"] == x["ref_id"] else 1 - r
+            x["ref_id"] = r
+        recs += part
+    recs.sort(key=lambda x: (x["ref_id"], x["pos"]))
+    batch = R.from_records(recs)
+    bed = {r: random_bed(rng, L, dense=(seed != 2))[0] for r, L in enumerate(ref_lens)}
+    kw = [dict(min_base_qual=20, mapq=0), dict(clip=4, min_base_qual=10, ignore_strand=1),
+          dict(strand_req=2, ignore_strand=1, mapq=20)][seed - 1]
+    opts = O.make_opts(max_read_len=100, max_read_span=150, **kw)
+    wr, wp, wv, woff, wf = O.pileup_per_read(opts, ref_lens, bed, batch)
+    with snp.PileupJob(opts, ref_lens) as job:
+        job.set_bed(bed)
+        job.submit(batch)
+        job.finish()
+        assert_same(job.rows(), (wr, wp, wv), "rows")
+        off, feats = job.per_read()
+        assert (off == woff).all()
+        assert feats.tobytes() == wf.tobytes()
+        assert len(feats) > 2000
+        # a sub-range of rows
+        o2, f2 = job.per_read(100, 50)
+        lo, hi = int(woff[400]), int(woff[600])
+        assert (o2 == woff[400:601] - woff[400]).all() and f2.tobytes() == wf[lo:hi].tobytes()
+    sopts = O.make_opts(max_read_len=100, max_read_span=150, stitch=1)
+    with snp.PileupJob(sopts, ref_lens) as job:
+        job.set_bed(bed)
+        job.submit(batch)
+        job.finish()
+        with pytest.raises(snp.PileupError, match="stitched per-read features not yet supported"):
+            job.per_read()

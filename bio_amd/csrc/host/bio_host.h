@@ -153,7 +153,10 @@ int BioPileupMain(int argc, char** argv);
 class RowWriter {
  public:
   virtual ~RowWriter() {}
-  virtual std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n) = 0;
+  // off/feats: per-read feature lists of the n rows (bp_per_read_offsets / _features; feats
+  // points at entry off[0]); both NULL unless a per-read column set was requested.
+  virtual std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
+                            const uint64_t* off, const bp_per_read* feats) = 0;
   virtual std::string Close() = 0;
 };
 // ConvertPileupRowsToTSV (output.go:42-300): <prefix>.ref.tsv[.gz] + <prefix>.alt.tsv[.gz]

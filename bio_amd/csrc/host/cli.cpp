@@ -60,8 +60,9 @@ int BioPileupMain(int argc, char** argv) {
       {"index", Flag::kString, &o.BamIndexPath, "Input BAM index path (accepted; the BAM is read sequentially)"},
       {"clip", Flag::kInt, &o.Clip, "Number of bases on end of each read to treat as minimum-quality"},
       {"cols", Flag::kString, &o.Cols,
-       "Output TSV column sets. #CHROM/POS/REF(/ALT) are always present. Supported optional sets are 'dpref', "
-       "'dpalt', 'highq', and 'lowq'; default is \"dpref,highq,lowq\""},
+       "Output TSV column sets. #CHROM/POS/REF(/ALT) are always present. Currently supported optional sets are "
+       "'dpref', 'dpalt', 'enddists', 'quals', 'fraglens', 'strands', 'highq', and 'lowq'; default is "
+       "\"dpref,highq,lowq\""},
       {"flag-exclude", Flag::kInt, &o.FlagExclude, "Reads with a FLAG bit intersecting this value are skipped"},
       {"format", Flag::kString, &format,
        "Output format; 'basestrand-tsv', 'basestrand-tsv-bgz', 'tsv', and 'tsv-bgz' supported"},

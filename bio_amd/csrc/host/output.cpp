@@ -18,6 +18,8 @@ namespace {
 const char kSeq8ToASCII[16] = {'=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'};  // common.go:72
 const uint8_t kSeq8ToEnum[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};                                 // common.go:66
 const char kEnumToASCII[5] = {'A', 'C', 'G', 'T', 'N'};                                                           // common.go:69
+const char kStrandToASCII[3] = {'.', '+', '-'};                                                                   // common.go:91
+constexpr int kPerReadMask = kColEndDists | kColQuals | kColFraglens | kColStrands;                               // pileup.go:146
 
 // Byte sink: plain file, or BGZF (public SAM-spec container: <=64 KiB gzip members with a
 // BC extra subfield and an empty EOF member), compressed a batch of blocks at a time.
@@ -128,6 +130,16 @@ class Tsv {
     while (n) buf_.push_back(t[--n]);
     buf_.push_back('\t');
   }
+  void WritePartial(const char* s, size_t n) { buf_.append(s, n); }
+  void WriteCsvUint32(uint32_t v) {
+    char t[12];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) buf_.push_back(t[--n]);
+    buf_.push_back(',');
+  }
+  void WriteCsvByte(char c) { buf_.push_back(c); buf_.push_back(','); }
+  void EndCsv() { if (!buf_.empty() && buf_.back() == ',') buf_.back() = '\t'; }
   std::string EndLine() {
     if (!buf_.empty() && buf_.back() == '\t') buf_.back() = '\n'; else buf_.push_back('\n');
     if (buf_.size() >= kFlush) return Flush();
@@ -178,14 +190,45 @@ class TsvWriter : public RowWriter {
     alt_.WriteString("#CHROM\tPOS\tREF\tALT");
     if (cols_ & kColDpRef) ref_.WriteString("DP");
     if (cols_ & kColDpAlt) alt_.WriteString("DP");
+    if (cols_ & kColEndDists) {  // output.go:93-114
+      ref_.WriteString("5P_DISTS\t3P_DISTS"); alt_.WriteString("5P_DISTS\t3P_DISTS");
+      empty_ += ".\t.\t";
+    }
+    if (cols_ & kColQuals) { ref_.WriteString("QUALS"); alt_.WriteString("QUALS"); empty_ += ".\t"; }
+    if (cols_ & kColFraglens) { ref_.WriteString("FRAGLENS"); alt_.WriteString("FRAGLENS"); empty_ += ".\t"; }
+    if (cols_ & kColStrands) { ref_.WriteString("STRANDS"); alt_.WriteString("STRANDS"); empty_ += ".\t"; }
     if (cols_ & kColHighQ) { ref_.WriteString("ref_depth_tier1"); alt_.WriteString("alt_depth_tier1"); }
     if (cols_ & kColLowQ) { ref_.WriteString("ref_depth_tier2"); alt_.WriteString("alt_depth_tier2"); }
     err = ref_.EndLine();
     if (!err.empty()) return err;
     return alt_.EndLine();
   }
-  std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n) override {
+  // per-read columns of one feature list (output.go:173-200, :235-262)
+  void WriteLists(Tsv& w, const bp_per_read* f, uint64_t m) {
+    if (cols_ & kColEndDists) {
+      for (uint64_t k = 0; k < m; k++) w.WriteCsvUint32(f[k].dist5p);
+      w.EndCsv();
+      for (uint64_t k = 0; k < m; k++) w.WriteCsvUint32((uint16_t)(f[k].fraglen - 1 - f[k].dist5p));
+      w.EndCsv();
+    }
+    if (cols_ & kColQuals) {
+      for (uint64_t k = 0; k < m; k++) w.WriteCsvUint32(f[k].qual);
+      w.EndCsv();
+    }
+    if (cols_ & kColFraglens) {
+      for (uint64_t k = 0; k < m; k++) w.WriteCsvUint32(f[k].fraglen);
+      w.EndCsv();
+    }
+    if (cols_ & kColStrands) {
+      for (uint64_t k = 0; k < m; k++) w.WriteCsvByte(kStrandToASCII[f[k].strand < 3 ? f[k].strand : 0]);
+      w.EndCsv();
+    }
+  }
+  std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
+                    const uint64_t* off, const bp_per_read* feats) override {
     std::string err;
+    const bool per_read = (cols_ & kPerReadMask) != 0;
+    if (per_read && (!off || (!feats && off[4 * n] != off[0]))) return "pileup output: per-read columns without feature lists";
     for (int64_t i = 0; i < n; i++) {
       const uint32_t* v = vals + i * BP_ROW_U32;
       uint8_t b8;
@@ -198,6 +241,11 @@ class TsvWriter : public RowWriter {
       ref_.WriteUint32((uint32_t)pos[i] + 1);
       ref_.WriteByte(ref_char);
       if (cols_ & kColDpRef) ref_.WriteUint32(v[0]);
+      if (per_read) {
+        const uint64_t m = ref_base == 4 ? 0 : off[4 * i + ref_base + 1] - off[4 * i + ref_base];
+        if (m == 0) ref_.WritePartial(empty_.data(), empty_.size());
+        else WriteLists(ref_, feats + (off[4 * i + ref_base] - off[0]), m);
+      }
       if (cols_ & kColHighQ) ref_.WriteUint32(v[1 + 2 * ref_base] + v[2 + 2 * ref_base]);
       if (cols_ & kColLowQ) ref_.WriteByte('0');
       err = ref_.EndLine();
@@ -211,6 +259,10 @@ class TsvWriter : public RowWriter {
         alt_.WriteByte(ref_char);
         alt_.WriteByte(kEnumToASCII[alt]);
         if (cols_ & kColDpAlt) alt_.WriteUint32(v[0]);
+        if (per_read) {
+          if (alt == 4) alt_.WritePartial(empty_.data(), empty_.size());
+          else WriteLists(alt_, feats + (off[4 * i + alt] - off[0]), off[4 * i + alt + 1] - off[4 * i + alt]);
+        }
         if (cols_ & kColHighQ) alt_.WriteUint32(c);
         if (cols_ & kColLowQ) alt_.WriteByte('0');
         err = alt_.EndLine();
@@ -228,20 +280,59 @@ class TsvWriter : public RowWriter {
   int cols_;
   Tsv ref_, alt_;
   RefLookup lk_;
+  std::string empty_;  // emptyPerReadStats (output.go:92-113)
 };
 
 class BasestrandTsvWriter : public RowWriter {
  public:
-  BasestrandTsvWriter(bool bgz, const std::vector<std::string>& names, const std::vector<const std::string*>& seqs)
-      : w_(bgz), lk_{names, seqs} {}
+  BasestrandTsvWriter(int cols, bool bgz, const std::vector<std::string>& names,
+                      const std::vector<const std::string*>& seqs)
+      : cols_(cols), w_(bgz), lk_{names, seqs} {}
   std::string Open(const std::string& main_path, bool bgz) {
     std::string err = w_.Open(main_path + ".basestrand.tsv" + (bgz ? ".gz" : ""));
     if (!err.empty()) return err;
     w_.WriteString("#CHROM\tPOS\tREF\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-");
+    // The per-read header pieces start with a tab AND go through WriteString (output.go:
+    // 405-418), which appends one: restated literally, so the header carries an empty column
+    // before each piece.  grailbio/base/tsv is not in the reference tree: parity unpinned.
+    static const char* kBS[8] = {"A+", "A-", "C+", "C-", "G+", "G-", "T+", "T-"};
+    auto piece = [&](const char* a, const char* b) {
+      std::string h;
+      for (const char* pre : {a, b}) {
+        if (!pre) continue;
+        for (int k = 0; k < 8; k++) h += std::string("\t") + pre + "_" + kBS[k];
+      }
+      w_.WriteString(h);
+      for (const char* pre : {a, b})
+        if (pre) for (int k = 0; k < 8; k++) empty_ += ".\t";
+    };
+    if (cols_ & kColEndDists) piece("5P_DISTS", "3P_DISTS");
+    if (cols_ & kColQuals) piece("QUALS", nullptr);
+    if (cols_ & kColFraglens) piece("FRAGLENS", nullptr);
+    if (cols_ & kColStrands) piece("STRANDS", nullptr);
     return w_.EndLine();
   }
-  std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n) override {
+  // one per-read column group over the four bases (output.go:463-552): values of forward-strand
+  // reads go to the + column, all others to the - column
+  template <class F>
+  void WriteGroup(const uint64_t* off4, const bp_per_read* feats, uint64_t base0, F value) {
+    for (int b = 0; b < 4; b++) {
+      const uint64_t m = off4[b + 1] - off4[b];
+      if (m == 0) { w_.WriteString(".\t."); continue; }
+      const bp_per_read* f = feats + (off4[b] - base0);
+      plus_.clear(); minus_.clear();
+      for (uint64_t k = 0; k < m; k++) value(f[k], f[k].strand == 1 ? plus_ : minus_);
+      for (std::string* sb : {&plus_, &minus_}) {  // flushPlusAndMinusBuf (output.go:359-374)
+        if (sb->empty()) { w_.WriteByte('.'); } else { w_.WritePartial(sb->data(), sb->size()); w_.EndCsv(); }
+      }
+    }
+  }
+  static void AppendUint(std::string& s, uint32_t v) { s += std::to_string(v); s.push_back(','); }
+  std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
+                    const uint64_t* off, const bp_per_read* feats) override {
     std::string err;
+    const bool per_read = (cols_ & kPerReadMask) != 0;
+    if (per_read && (!off || (!feats && off[4 * n] != off[0]))) return "pileup output: per-read columns without feature lists";
     for (int64_t i = 0; i < n; i++) {
       const uint32_t* v = vals + i * BP_ROW_U32;
       uint8_t b8;
@@ -251,6 +342,27 @@ class BasestrandTsvWriter : public RowWriter {
       w_.WriteUint32((uint32_t)pos[i] + 1);
       w_.WriteByte(kSeq8ToASCII[b8 & 15]);
       for (int k = 0; k < 8; k++) w_.WriteUint32(v[1 + k]);
+      if (per_read) {
+        if (v[0] == 0) {
+          w_.WritePartial(empty_.data(), empty_.size());
+        } else {
+          const uint64_t* o4 = off + 4 * i;
+          if (cols_ & kColEndDists) {
+            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.dist5p); });
+            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) {
+              AppendUint(s, (uint16_t)(f.fraglen - 1 - f.dist5p));
+            });
+          }
+          if (cols_ & kColQuals)
+            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.qual); });
+          if (cols_ & kColFraglens)
+            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.fraglen); });
+          if (cols_ & kColStrands)
+            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) {
+              s += f.strand == 1 ? "+," : "-,";
+            });
+        }
+      }
       err = w_.EndLine();
       if (!err.empty()) return err;
     }
@@ -259,8 +371,10 @@ class BasestrandTsvWriter : public RowWriter {
   std::string Close() override { return w_.Close(); }
 
  private:
+  int cols_;
   Tsv w_;
   RefLookup lk_;
+  std::string empty_, plus_, minus_;
 };
 
 }  // namespace
@@ -278,8 +392,7 @@ std::unique_ptr<RowWriter> NewBasestrandTsvWriter(const std::string& main_path, 
                                                   const std::vector<std::string>& ref_names,
                                                   const std::vector<const std::string*>& ref_seqs,
                                                   std::string* err) {
-  (void)col_bitset;  // per-read column sets are rejected before a writer is made
-  std::unique_ptr<BasestrandTsvWriter> w(new BasestrandTsvWriter(bgzip, ref_names, ref_seqs));
+  std::unique_ptr<BasestrandTsvWriter> w(new BasestrandTsvWriter(col_bitset, bgzip, ref_names, ref_seqs));
   *err = w->Open(main_path, bgzip);
   if (!err->empty()) return nullptr;
   return std::unique_ptr<RowWriter>(w.release());

@@ -80,6 +80,7 @@ class Driver {
       : opts_(o), hd_(hd), bed_(bed), ignore_strand_(fmt_ignore_strand) {}
 
   std::vector<Stream> streams;
+  bool per_read = false;  // a per-read column set is requested (pCtx.perReadNeeded)
 
   void SetPadding(int64_t bed_pad) { bed_pad_ = bed_pad; }
 
@@ -119,19 +120,36 @@ class Driver {
   }
 
   std::string CloseJob(const Job& j) {
-    std::vector<int32_t> ref(kRowChunk), pos(kRowChunk);
-    std::vector<uint32_t> vals((size_t)kRowChunk * BP_ROW_U32);
+    // per-read lists can be long: smaller row chunks keep the host copies bounded
+    const int64_t chunk = per_read ? (kRowChunk >> 6) : kRowChunk;
+    std::vector<int32_t> ref((size_t)chunk), pos((size_t)chunk);
+    std::vector<uint32_t> vals((size_t)chunk * BP_ROW_U32);
+    std::vector<uint64_t> off;
+    std::vector<bp_per_read> feats;
     for (Stream& s : streams) {
       if (bp_finish(s.h) != BP_OK) return HandleErr(s.h);
+      if (per_read && bp_per_read_build(s.h) != BP_OK) return HandleErr(s.h);
       const int64_t n = bp_num_rows(s.h);
-      for (int64_t first = 0; first < n; first += kRowChunk) {
-        const int64_t m = std::min(kRowChunk, n - first);
+      for (int64_t first = 0; first < n; first += chunk) {
+        const int64_t m = std::min(chunk, n - first);
         if (bp_rows(s.h, first, m, ref.data(), pos.data(), vals.data()) != BP_OK) return HandleErr(s.h);
         // rows of the padding belong to the neighbouring jobs
         const int64_t lo = std::lower_bound(pos.begin(), pos.begin() + m, j.start) - pos.begin();
         const int64_t hi = std::lower_bound(pos.begin(), pos.begin() + m, j.end) - pos.begin();
         if (lo >= hi) continue;
-        std::string err = s.writer->Write(ref.data() + lo, pos.data() + lo, vals.data() + lo * BP_ROW_U32, hi - lo);
+        const uint64_t* offp = nullptr;
+        const bp_per_read* featp = nullptr;
+        if (per_read) {
+          off.resize((size_t)(4 * (hi - lo) + 1));
+          if (bp_per_read_offsets(s.h, first + lo, hi - lo, off.data()) != BP_OK) return HandleErr(s.h);
+          feats.resize((size_t)(off.back() - off.front()));
+          if (bp_per_read_features(s.h, off.front(), off.back() - off.front(), feats.data()) != BP_OK)
+            return HandleErr(s.h);
+          offp = off.data();
+          featp = feats.data();
+        }
+        std::string err = s.writer->Write(ref.data() + lo, pos.data() + lo, vals.data() + lo * BP_ROW_U32, hi - lo,
+                                          offp, featp);
         if (!err.empty()) return err;
       }
       bp_destroy(s.h);
@@ -235,11 +253,14 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   if (fmt == kRio)
     return "Pileup: basestrand-rio output is not supported by this build (the recordio container lives in "
            "grailbio/base, which the reference tree does not include); use basestrand-tsv";
-  if (cols & (kColEndDists | kColQuals | kColFraglens | kColStrands))
-    return "Pileup: per-read column sets (enddists, quals, fraglens, strands) are not supported by this build";
+  const bool per_read = (cols & (kColEndDists | kColQuals | kColFraglens | kColStrands)) != 0;  // pileup.go:888
+  if (per_read && opts.Stitch)
+    // the reference panics at the first pair it merges (pileup.go:422-443); refused up front
+    return "stitched per-read features not yet supported";
   if (bp_init(opts.Device) != BP_OK) return bp_last_error(nullptr);
 
   Driver drv(opts, hd, bed, tsv_format ? 1 : 0);
+  drv.per_read = per_read;
   const int n_stream = opts.PerStrand ? 2 : 1;
   drv.streams.resize((size_t)n_stream);
   for (int s = 0; s < n_stream; s++) {

@@ -75,6 +75,109 @@ def render_basestrand(rows, ref_names, ref_ascii):
     return "\n".join(out) + "\n"
 
 
+def _lists_cols(cols, f):
+    """per-read columns of one feature list (output.go:173-200)"""
+    out = []
+    if cols & host.COL_ENDDISTS:
+        out.append(",".join(str(int(x["dist5p"])) for x in f))
+        out.append(",".join(str((int(x["fraglen"]) - 1 - int(x["dist5p"])) & 0xFFFF) for x in f))
+    if cols & host.COL_QUALS:
+        out.append(",".join(str(int(x["qual"])) for x in f))
+    if cols & host.COL_FRAGLENS:
+        out.append(",".join(str(int(x["fraglen"])) for x in f))
+    if cols & host.COL_STRANDS:
+        out.append(",".join(".+-"[int(x["strand"])] for x in f))
+    return out
+
+
+def _n_per_read_cols(cols):
+    return (2 * bool(cols & host.COL_ENDDISTS) + bool(cols & host.COL_QUALS) + bool(cols & host.COL_FRAGLENS) +
+            bool(cols & host.COL_STRANDS))
+
+
+def render_tsv_per_read(res, ref_names, ref_ascii, cols):
+    """output.go:83-131 header, :149-275 body with per-read column sets -> (ref text, alt text)"""
+    ref, pos, vals, off, feats = res
+    hr, ha = ["#CHROM", "POS", "REF"], ["#CHROM", "POS", "REF", "ALT"]
+    if cols & host.COL_DPREF:
+        hr.append("DP")
+    if cols & host.COL_DPALT:
+        ha.append("DP")
+    for bit, names in ((host.COL_ENDDISTS, ["5P_DISTS", "3P_DISTS"]), (host.COL_QUALS, ["QUALS"]),
+                       (host.COL_FRAGLENS, ["FRAGLENS"]), (host.COL_STRANDS, ["STRANDS"])):
+        if cols & bit:
+            hr += names
+            ha += names
+    if cols & host.COL_HIGHQ:
+        hr.append("ref_depth_tier1"); ha.append("alt_depth_tier1")
+    if cols & host.COL_LOWQ:
+        hr.append("ref_depth_tier2"); ha.append("alt_depth_tier2")
+    empty = ["."] * _n_per_read_cols(cols)
+    out_r, out_a = ["\t".join(hr)], ["\t".join(ha)]
+    for i in range(len(pos)):
+        name = ref_names[ref[i]]
+        b8 = ASCII_SEQ8.get(ref_ascii[ref[i]][pos[i]], 15)
+        ch, rb = SEQ8_ASCII[b8], SEQ8_ENUM[b8]
+        v = [int(x) for x in vals[i]]
+        cnt = [v[1 + 2 * b] + v[2 + 2 * b] for b in range(5)]
+        lists = [feats[int(off[4 * i + b]):int(off[4 * i + b + 1])] for b in range(4)]
+        f = [name, str(pos[i] + 1), ch]
+        if cols & host.COL_DPREF:
+            f.append(str(v[0]))
+        f += empty if rb == 4 or len(lists[rb]) == 0 else _lists_cols(cols, lists[rb])
+        if cols & host.COL_HIGHQ:
+            f.append(str(cnt[rb]))
+        if cols & host.COL_LOWQ:
+            f.append("0")
+        out_r.append("\t".join(f))
+        for alt in range(5):
+            if alt == rb or cnt[alt] == 0:
+                continue
+            f = [name, str(pos[i] + 1), ch, "ACGTN"[alt]]
+            if cols & host.COL_DPALT:
+                f.append(str(v[0]))
+            f += empty if alt == 4 else _lists_cols(cols, lists[alt])
+            if cols & host.COL_HIGHQ:
+                f.append(str(cnt[alt]))
+            if cols & host.COL_LOWQ:
+                f.append("0")
+            out_a.append("\t".join(f))
+    return "\n".join(out_r) + "\n", "\n".join(out_a) + "\n"
+
+
+def render_basestrand_per_read(res, ref_names, ref_ascii, cols):
+    """output.go:400-421 header (each per-read piece starts with a tab and gets another from
+    WriteString), :445-553 body"""
+    ref, pos, vals, off, feats = res
+    bs = ["A+", "A-", "C+", "C-", "G+", "G-", "T+", "T-"]
+    hdr = "#CHROM\tPOS\tREF\t" + "\t".join(bs)
+    groups = []
+    for bit, names in ((host.COL_ENDDISTS, ["5P_DISTS", "3P_DISTS"]), (host.COL_QUALS, ["QUALS"]),
+                       (host.COL_FRAGLENS, ["FRAGLENS"]), (host.COL_STRANDS, ["STRANDS"])):
+        if cols & bit:
+            hdr += "\t" + "".join("\t%s_%s" % (n, b) for n in names for b in bs)
+            groups += names
+    out = [hdr]
+    val = {"5P_DISTS": lambda x: str(int(x["dist5p"])),
+           "3P_DISTS": lambda x: str((int(x["fraglen"]) - 1 - int(x["dist5p"])) & 0xFFFF),
+           "QUALS": lambda x: str(int(x["qual"])), "FRAGLENS": lambda x: str(int(x["fraglen"])),
+           "STRANDS": lambda x: "+" if int(x["strand"]) == 1 else "-"}
+    for i in range(len(pos)):
+        b8 = ASCII_SEQ8.get(ref_ascii[ref[i]][pos[i]], 15)
+        f = [ref_names[ref[i]], str(pos[i] + 1), SEQ8_ASCII[b8]] + [str(int(x)) for x in vals[i][1:9]]
+        if int(vals[i][0]) == 0:
+            f += ["."] * (8 * len(groups))
+        else:
+            for g in groups:
+                for b in range(4):
+                    lst = feats[int(off[4 * i + b]):int(off[4 * i + b + 1])]
+                    plus = [val[g](x) for x in lst if int(x["strand"]) == 1]
+                    minus = [val[g](x) for x in lst if int(x["strand"]) != 1]
+                    f += [",".join(plus) or ".", ",".join(minus) or "."] if len(lst) else [".", "."]
+        out.append("\t".join(f))
+    return "\n".join(out) + "\n"
+
+
 class Case:
     def __init__(self, tmp_path, seed=11, n_pairs=2500, ref_lens=(9000, 4000, 6000, 3000), read_len=100,
                  bed_refs=(0, 1, 3), aux=False):
@@ -237,3 +340,36 @@ def test_cli_binary(tmp_path):
     assert r.returncode == 0, r.stderr
     want = c.oracle(stitch=1, min_base_qual=20)
     assert c.read("cli.basestrand.tsv") == render_basestrand(want, c.ref_names, c.ref_ascii)
+
+
+def test_per_read_column_sets(tmp_path, monkeypatch):
+    """-cols with enddists / quals / fraglens / strands (appendBase, pileup.go:235-250; rendering
+    output.go:165-203, :230-264, :454-553).  The reference's own expected files use
+    enddists,strands (ordered2.*.expected) and dpref,quals,fraglens."""
+    c = Case(tmp_path, seed=21)
+    out = str(tmp_path / "pr")
+    kw = dict(max_read_len=500, max_read_span=511)
+    for cols_arg, cols, okw, pkw in (
+            ("enddists,strands", host.COL_ENDDISTS | host.COL_STRANDS, dict(Mapq=60), dict(mapq=60)),
+            ("dpref,quals,fraglens", host.COL_DPREF | host.COL_QUALS | host.COL_FRAGLENS,
+             dict(Mapq=0, MinBaseQual=20, Clip=5), dict(mapq=0, min_base_qual=20, clip=5)),
+            ("+dpalt,+strands", host.COLS_DEFAULT | host.COL_DPALT | host.COL_STRANDS, dict(Mapq=30), dict(mapq=30))):
+        host.pileup(c.bam, c.fa, "tsv", out, Opts(BedPath=c.bed_path, Cols=cols_arg, **okw))
+        want = O.pileup_per_read(O.make_opts(ignore_strand=1, **kw, **pkw), c.ref_lens, c.bed, c.batch)
+        wr, wa = render_tsv_per_read(want, c.ref_names, c.ref_ascii, cols)
+        assert c.read("pr.ref.tsv") == wr, cols_arg
+        assert c.read("pr.alt.tsv") == wa, cols_arg
+        assert wr.count(",") > 1000
+    # basestrand-tsv with every per-read set, whole contigs and cut into small jobs
+    allc = host.COL_ENDDISTS | host.COL_QUALS | host.COL_FRAGLENS | host.COL_STRANDS
+    want = render_basestrand_per_read(O.pileup_per_read(O.make_opts(mapq=20, **kw), c.ref_lens, c.bed, c.batch),
+                                      c.ref_names, c.ref_ascii, allc)
+    for span in (None, 600):
+        if span:
+            monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(span))
+        host.pileup(c.bam, c.fa, "basestrand-tsv", out,
+                    Opts(BedPath=c.bed_path, Cols="enddists,quals,fraglens,strands", Mapq=20))
+        assert c.read("pr.basestrand.tsv") == want, span
+    monkeypatch.delenv("BIO_PILEUP_JOB_SPAN")
+    with pytest.raises(PileupError, match="stitched per-read features not yet supported"):
+        host.pileup(c.bam, c.fa, "tsv", out, Opts(BedPath=c.bed_path, Cols="quals", Stitch=True))

@@ -216,7 +216,7 @@ def _inputs(tmp_path, ref_len=20000, fa_len=None):
     (dict(Region="chrT", PerStrand=True), "basestrand-tsv", "single-strand mode not supported with basestrand output"),
     (dict(Region="chrT", MinBaseQual=96), "tsv", "newQualPassTable: minBaseQual too large"),
     (dict(Region="chrT"), "basestrand-rio", "basestrand-rio output is not supported by this build"),
-    (dict(Region="chrT", Cols="quals"), "tsv", "per-read column sets"),
+    (dict(Region="chrT", Cols="quals", Stitch=True), "tsv", "stitched per-read features not yet supported"),
 ])
 def test_pileup_option_errors(tmp_path, kw, fmt, msg):
     bam, fa, bed = _inputs(tmp_path)

@@ -64,12 +64,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pileup path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
+    # multi-rank flow on a single-GPU box (the ranks' only traffic is two scalar reductions)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from bio_amd import _abi, snp, synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -77,7 +84,7 @@ def main():
     L = args.length
     opts_kw = dict(flag_exclude=0xF00, mapq=60)
     o = snp.Opts()  # DefaultOpts
-    bopts = snp.device_opts(o, "basestrand-tsv", device=local_rank)
+    bopts = snp.device_opts(o, "basestrand-tsv", device=dev_index)
 
     t0 = time.time()
     threads = min(16, os.cpu_count() or 1)
@@ -116,7 +123,7 @@ def main():
     if dist is not None:
         # the only communication of a multi-GPU run: MAX of elapsed, SUM of bases
         from bio_amd import partition
-        elapsed, total_B = partition.reduce_timing(dist, elapsed, B, device="cuda")
+        elapsed, total_B = partition.reduce_timing(dist, elapsed, B, device="cuda" if backend == "nccl" else "cpu")
     else:
         total_B = B
 

@@ -156,6 +156,11 @@ struct SegExtra {
   uint32_t s_lenq0[kSegCap];    // length | read offset << 16
   uint32_t s_lseqnc[kSegCap];   // l_seq | n_cigar << 16
   int32_t s_rec[kSegCap];       // record index
+  // the record's mate (stitch): x = mate start relative to the window start, y = span |
+  // single-M-op << 16 | this record is the one that found its mate << 17 | has a mate << 18,
+  // z = mate payload offset, w = mate l_seq | n_cigar << 16
+  uint4 s_mate[kSegCap];
+  uint8_t qthr[96];             // copy of KernelParams::qthr
 };
 struct NoExtra {};
 
@@ -185,6 +190,28 @@ __device__ int32_t read_index_at(const ReadCore& c, const uint8_t* blob, int32_t
   const uint32_t* cg = (const uint32_t*)(blob + (uint64_t)c.blob * 8);
   int32_t r = c.pos, q = 0;
   for (uint32_t k = 0; k < c.n_cigar; k++) {
+    uint32_t op = cg[k] & 15u;
+    int32_t len = (int32_t)(cg[k] >> 4);
+    if (op == 0) {
+      if (rp >= r && rp < r + len) return q + (rp - r);
+      r += len; q += len;
+    } else if (op == 1 || op == 4) {
+      q += len;
+    } else if (op == 2 || op == 3) {
+      r += len;
+    } else if (op != 5) {
+      break;
+    }
+    if (r > rp) break;
+  }
+  return -1;
+}
+
+// The same walk on window-relative coordinates: `rel` = record start - window start.
+__device__ int32_t read_index_rel(int32_t rel, uint32_t n_cigar, const uint8_t* payload, int32_t rp) {
+  const uint32_t* cg = (const uint32_t*)payload;
+  int32_t r = rel, q = 0;
+  for (uint32_t k = 0; k < n_cigar; k++) {
     uint32_t op = cg[k] & 15u;
     int32_t len = (int32_t)(cg[k] >> 4);
     if (op == 0) {
@@ -245,7 +272,7 @@ __device__ __forceinline__ bool seg_extent(const SegIn& g, uint32_t wlen, int32_
 template <bool EXTRA>
 __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, uint32_t us, const SegIn& g,
                                           int32_t s1, int32_t e1, uint32_t jlo, uint32_t U, uint32_t blob,
-                                          uint32_t lseqnc, uint32_t sslot, int32_t rec) {
+                                          uint32_t lseqnc, uint32_t sslot, int32_t rec, uint4 minfo) {
   // byte offsets inside the record payload [cigar padded to even][qual 8*Ur][seq 4*Ur]
   const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
   const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
@@ -267,6 +294,7 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
     S.ex.s_lenq0[idx] = (uint32_t)g.len | ((uint32_t)g.q0 << 16);
     S.ex.s_lseqnc[idx] = lseqnc;
     S.ex.s_rec[idx] = rec;
+    S.ex.s_mate[idx] = minfo;
   }
   for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
 }
@@ -279,7 +307,7 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
 template <bool EXTRA>
 __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
                                           const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
-                                          uint32_t sslot, int32_t rec, uint32_t par) {
+                                          uint32_t sslot, int32_t rec, uint32_t par, uint4 minfo) {
   int32_t s1A, e1A, s1B, e1B;
   uint32_t jloA, UA, jloB, UB;
   const bool realA = seg_extent(A, wlen, s1A, e1A, jloA, UA) && wantA;  // clipped-away segments need no slot
@@ -301,8 +329,8 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
   const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
   const bool ok = idx + nseg <= (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
   if (ok) {
-    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, sslot, rec);
-    if (realB) write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, sslot, rec);
+    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, sslot, rec, minfo);
+    if (realB) write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, sslot, rec, minfo);
   } else {
     for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
   }
@@ -311,7 +339,7 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
 
 // One unit in flight: the loaded bytes and everything processing needs, so that the plain
 // path does not touch the segment list again.
-template <bool NEED_Q>
+template <bool NEED_Q, bool STITCH = false>
 struct UnitLoad {
   uint32_t sd[5];                  // 20 bytes covering the unit's 32 packed bases
   uint32_t qd[NEED_Q ? 9 : 1];     // 36 bytes covering the unit's 32 quals
@@ -319,6 +347,11 @@ struct UnitLoad {
   uint32_t meta;                   // 0..5 window unit | 6..8 nibble shift | 9..10 qual byte shift |
                                    // 11 strand slot | 16 active
   uint32_t seg;                    // segment (stitched / clipped paths)
+  // stitch, mate that is one M op, this record being the one that found its mate: the mate's
+  // quals and bases over the same 32 positions, and which of them the mate covers
+  uint32_t mq[STITCH ? 9 : 1], ms[STITCH ? 5 : 1];
+  uint32_t ov32;
+  uint32_t msh;                    // 0..1 mate qual byte shift | 2..6 4 * mate nibble shift
 };
 
 // Byte offsets, inside a record's payload, of the unit's first qual / first packed base.
@@ -333,9 +366,9 @@ __device__ __forceinline__ void unit_offsets(uint32_t lseqnc, int32_t b0, int32_
 // that every issue is the same number of VMEM instructions and the counted vmcnt waits stay
 // exact.  NEED_Q = false (min_base_qual 0, no stitching: every base passes the quality rule,
 // pileup.go:227) skips the qual loads altogether.
-template <bool NEED_Q, bool EXTRA>
+template <bool NEED_Q, bool STITCH, bool EXTRA>
 __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<EXTRA>& S, uint32_t t,
-                                           uint32_t T, uint32_t R, UnitLoad<NEED_Q>& L) {
+                                           uint32_t T, uint32_t R, UnitLoad<NEED_Q, STITCH>& L) {
   // Slot order: neighbouring segments overlap on the genome, and lanes of one instruction
   // that add to the same counter serialise.  Chunks of BP_CHUNK consecutive slots (part of
   // one segment: distinct units, consecutive banks) are dealt out column-wise over a
@@ -377,6 +410,42 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
   const u32x4a s0 = *(const u32x4a*)sp;
   L.sd[4] = *(const uint32_t*)(sp + 16);
   L.sd[0] = s0.x; L.sd[1] = s0.y; L.sd[2] = s0.z; L.sd[3] = s0.w;
+  if constexpr (STITCH) {
+    // For a mate that is one M op the positions both reads cover are a range of the unit: the
+    // record stored first simply drops them (pileup.go:409-430: Depth++ once, by the record
+    // that found its mate); that one fetches the mate's quals and bases over the unit now,
+    // with the same wide loads as its own.
+    const uint4 mi4 = S.ex.s_mate[s];
+    const bool mhas = in && (mi4.y & 0x40000u) != 0;
+    const bool msimple = (mi4.y & 0x10000u) != 0, second = (mi4.y & 0x20000u) != 0;
+    const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x;  // mate read index of the unit's position 0
+    uint32_t ov = 0;
+    if (mhas && msimple) {
+      const int32_t lo = -mi0, hi = lo + (int32_t)(mi4.y & 0xffffu);
+      const int32_t l2 = lo > 0 ? lo : 0, h2 = hi < 32 ? hi : 32;
+      if (h2 > l2) ov = (h2 - l2 >= 32 ? 0xffffffffu : ((1u << (h2 - l2)) - 1u) << l2);
+      if (!second) { L.mask &= ~ov; ov = 0; }
+    }
+    ov &= L.mask;
+    L.ov32 = ov;
+    L.meta |= (mhas && !msimple ? 0x20000u : 0u) | (second ? 0x40000u : 0u);
+    const uint32_t mlseqnc = mi4.w;
+    const int32_t mcig = (int32_t)((((mlseqnc >> 16) + 1u) & ~1u) * 4);
+    const int32_t qo = mcig + mi0;  // >= -23: the payload buffer starts with a pad
+    const int32_t so = mcig + (int32_t)((((mlseqnc & 0xffffu) + 7) >> 3) * 8) + (mi0 >> 1);
+    L.msh = ((uint32_t)qo & 3u) | ((2u * ((uint32_t)so & 3u) + ((uint32_t)mi0 & 1u)) << 4);
+    const uint8_t* mb = P.blob + (ov ? (uint64_t)mi4.z * 8 : 64);
+    const uint8_t* mqp = mb + (ov ? (qo & ~3) : 0);
+    const uint8_t* msp = mb + (ov ? (so & ~3) : 0);
+    const u32x4a a0 = *(const u32x4a*)mqp;
+    const u32x4a a1 = *(const u32x4a*)(mqp + 16);
+    L.mq[8] = *(const uint32_t*)(mqp + 32);
+    const u32x4a b0 = *(const u32x4a*)msp;
+    L.ms[4] = *(const uint32_t*)(msp + 16);
+    L.mq[0] = a0.x; L.mq[1] = a0.y; L.mq[2] = a0.z; L.mq[3] = a0.w;
+    L.mq[4] = a1.x; L.mq[5] = a1.y; L.mq[6] = a1.z; L.mq[7] = a1.w;
+    L.ms[0] = b0.x; L.ms[1] = b0.y; L.ms[2] = b0.z; L.ms[3] = b0.w;
+  }
 }
 
 // The plain path: no stitching.  The unit's 32 positions are handled as 4 groups of 8; the 8
@@ -386,12 +455,27 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
 // Seq8ToEnumTable (pileup/common.go:66): a nibble with exactly one bit set is a base
 // (log2 = its code); every other value is X.  A base failing the quality rule goes to the
 // depth-only planes, X is counted regardless (addBase, pileup.go:223-231).
-template <bool CLIP, bool MINQ0>
-__device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockSharedT<CLIP>& B,
-                                                   const UnitLoad<!MINQ0>& L) {
+//
+// Stitched runs take the same path: the codes of a group are computed as if every base stood
+// alone, and only the positions the record's mate also covers are patched afterwards
+// (addReadPair, pileup.go:406-446): the record that was stored first drops them, the one that
+// found its mate decides them from both reads (equal bases: qualSumTable threshold, else X).
+template <bool STITCH, bool CLIP, bool MINQ0>
+__device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
+                                                   const UnitLoad<STITCH || !MINQ0, STITCH>& L) {
+  static_assert(!(STITCH && MINQ0), "the stitched path always reads the quals");
   constexpr uint32_t M1 = 0x11111111u;
   const uint32_t meta = L.meta;
+  // mate of the record (prepared in phase 1)
+  uint4 mi4 = make_uint4(0, 0, 0, 0);
   const uint32_t jj = meta & 0x3fu;
+  uint32_t vmask = L.mask;  // positions still to be counted
+  const uint32_t ov32 = L.ov32;
+  bool mslow = false;  // mate with a longer CIGAR: per-base walk
+  if constexpr (STITCH) {
+    mi4 = B.ex.s_mate[L.seg];
+    mslow = (meta & 0x20000u) != 0;
+  }
   const uint32_t* const x = L.sd;  // base k of a dword at bits 4k (the packer stores it that way)
   const uint32_t nsh = (meta >> 4) & 0x1cu;  // 4 * nibble shift
   const uint32_t cbase = (jj + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
@@ -440,156 +524,98 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
       }
       const uint32_t pn15 = (pn << 4) - pn;     // 0xf per passing base
       const uint32_t cf = 0x44444444u | oh;     // failing: base -> depth-only (5), X stays X (4)
+      const uint32_t cpass = cw;
       cw = (cw & pn15) | (cf & ~pn15);
+      if constexpr (STITCH) {
+        const int32_t Pw = (int32_t)((4 * jj + m) * 8);
+        // own clipped quals are needed again below
+        int32_t b0 = 0, lseq = 0;
+        if constexpr (CLIP) {
+          const uint32_t sg = L.seg;
+          b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + (Pw - B.ex.s_ref[sg]);
+          lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
+        }
+        const uint32_t mls = mi4.w & 0xffffu;
+        // decide one position both reads cover (pileup.go:409-430), given the mate's base
+        // (BAM code) and quality there
+        auto decide = [&](int k, uint32_t mnib, uint32_t mq, int32_t mi) {
+          uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
+          if constexpr (CLIP) {
+            q = clipped_qual(q, b0 + k, lseq, P.clip);
+            mq = clipped_qual(mq, mi, (int32_t)mls, P.clip);
+          }
+          uint32_t code = 4u;  // the reads disagree: X
+          if (mnib == ((sw >> (4 * k)) & 15u)) {
+            if (q >= 96u || mq >= 96u) {
+              // qualPassTable index out of range: a Go runtime panic in the reference
+              atomicMin(&P.err->read, B.ex.s_rec[L.seg]);
+              vmask &= ~(1u << (8 * m + k));
+              return;
+            }
+            code = ((mq >= (uint32_t)B.ex.qthr[q] ? cpass : cf) >> (4 * k)) & 7u;
+          }
+          cw = (cw & ~(0xfu << (4 * k))) | (code << (4 * k));
+        };
+#ifdef BP_EXP_NODECIDE
+        const uint32_t ovg = 0;
+#else
+        const uint32_t ovg = ((ov32 & vmask) >> (8 * m)) & 0xffu;
+#endif
+        if (ovg) {
+          const uint32_t mqlo = __builtin_amdgcn_alignbyte(L.mq[2 * m + 1], L.mq[2 * m], L.msh & 3u);
+          const uint32_t mqhi = __builtin_amdgcn_alignbyte(L.mq[2 * m + 2], L.mq[2 * m + 1], L.msh & 3u);
+          const uint32_t msw = __builtin_amdgcn_alignbit(L.ms[m + 1], L.ms[m], (L.msh >> 2) & 0x1cu);
+          const int32_t mi0 = Pw - (int32_t)mi4.x;
+          // (rare, so one rolled copy: unrolling this and the loop below bloated the kernel
+          // past the instruction cache and cost 4x)
+#pragma unroll 1
+          for (int k = 0; k < 8; k++)
+            if ((ovg >> k) & 1u)
+              decide(k, (msw >> (4 * k)) & 15u, ((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu, mi0 + k);
+        }
+        const int32_t mrel = (int32_t)mi4.x, mspan = (int32_t)(mi4.y & 0xffffu);
+#ifdef BP_EXP_NOSLOW
+        if (false && Pw + 8 > mrel
+#else
+        if (mslow && Pw + 8 > mrel
+#endif
+ && Pw < mrel + mspan && ((vmask >> (8 * m)) & 0xffu)) {
+          const bool second = (mi4.y & 0x20000u) != 0;
+          const uint8_t* mb = P.blob + (uint64_t)mi4.z * 8;
+          const uint32_t mcig = ((((mi4.w >> 16)) + 1u) & ~1u) * 4;
+#pragma unroll 1
+          for (int k = 0; k < 8; k++) {
+            if (!((vmask >> (8 * m + k)) & 1u)) continue;
+            const int32_t mi = read_index_rel(mrel, mi4.w >> 16, mb, Pw + k);
+            if (mi < 0) continue;
+            if (!second) {
+              vmask &= ~(1u << (8 * m + k));
+              continue;
+            }
+            const uint32_t mbyte = mb[mcig + 8 * ((mls + 7) >> 3) + (mi >> 1)];
+            decide(k, (mi & 1) ? (mbyte >> 4) : (mbyte & 15u), mb[mcig + mi], mi);
+          }
+        }
+      }
     }
     // lanes without a unit (or without a valid base in this group) sit the atomics out:
     // they would all add 0 to one address and serialise the whole instruction
-    if ((L.mask >> (8 * m)) & 0xffu) {
+    if ((vmask >> (8 * m)) & 0xffu) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const uint32_t c = (cw >> (4 * k)) & 7u;
-        const uint32_t val = (L.mask >> (8 * m + k)) & 1u;
+        const uint32_t val = (vmask >> (8 * m + k)) & 1u;
         atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + cbase + (8 * m + k) * kSub * 4), val);
       }
     }
   }
 }
 
-// 8 positions of a unit, as the stitched path handles them
-struct Group8 {
-  uint32_t q0, q1, q2;  // 12 bytes covering the 8 quals
-  uint32_t s0, s1;      // 8 bytes covering the 8 packed bases
-  uint32_t seg;         // segment | active << 16
-  uint32_t jj;          // window positions 8*jj .. 8*jj+7
-  uint32_t sslot;
-};
-
-template <bool STITCH, bool CLIP>
-__device__ __forceinline__ void process_unit(const KernelParams& P, BlockSharedT<true>& B,
-                                             const Group8& L, uint32_t wlen, int32_t g0) {
-  const bool in = (L.seg & 0x10000u) != 0;
-  const uint32_t s = L.seg & 0xffffu;
-  const int32_t sref = B.ex.s_ref[s];
-  const uint32_t lenq0 = B.ex.s_lenq0[s];
-  const uint32_t lseqnc = B.ex.s_lseqnc[s];
-  const int32_t Pw = (int32_t)(L.jj * 8);
-  const int32_t len = (int32_t)(lenq0 & 0xffffu);
-  const uint32_t lseq = lseqnc & 0xffffu;
-  const int32_t b0 = (int32_t)(lenq0 >> 16) + (Pw - sref);
-  int32_t qoff, soff;
-  unit_offsets(lseqnc, b0, qoff, soff);
-  // which of the 8 positions belong to the segment and the window
-  int32_t klo = sref - Pw;
-  klo = klo > 0 ? klo : 0;
-  klo = klo < 8 ? klo : 8;
-  int32_t e = sref + len;
-  e = e < (int32_t)wlen ? e : (int32_t)wlen;
-  int32_t khi = e - Pw;
-  khi = khi < 8 ? khi : 8;
-  khi = khi > 0 ? khi : 0;
-  uint32_t mask = ((1u << khi) - 1u) & ~((1u << klo) - 1u);
-  mask = in ? mask : 0u;
-  // 8 quals and 8 nibbles, realigned to the unit
-  const uint32_t qsh = (uint32_t)qoff & 3u;
-  const uint32_t qlo = __builtin_amdgcn_alignbyte(L.q1, L.q0, qsh);
-  const uint32_t qhi = __builtin_amdgcn_alignbyte(L.q2, L.q1, qsh);
-  const uint32_t x0 = L.s0, x1 = L.s1;  // base k of a dword at bits 4k
-  const uint32_t noff = 2u * ((uint32_t)soff & 3u) + ((uint32_t)b0 & 1u);
-  const uint32_t sw = __builtin_amdgcn_alignbit(x1, x0, 4u * noff);
-  uint32_t sslot_u = L.sslot;
-  const uint32_t minq = (uint32_t)P.min_base_qual;
-  const int32_t clip = P.clip;
-
-  int32_t mate_idx = -1;
-  bool second = false;
-  ReadCore mc;
-  int32_t myrec = 0;
-  if constexpr (STITCH) {
-    if (in) {
-      myrec = B.ex.s_rec[s];
-      const int32_t m = P.mate[myrec];
-      if (m >= 0) {
-        mate_idx = m >> 1;
-        second = (m & 1) != 0;
-        mc = P.cores[mate_idx];
-        // the pair is counted on the strand of the read that found its mate
-        // (pileup.go:799-802); for the stored read that is the mate's strand
-        if (!second && !P.ignore_strand)
-          sslot_u = (uint32_t)(strand_of((mc.aux & AUX_MATE_SAME) != 0, mc.flags) - 1) & 1u;
-      }
-    }
-  }
-  uint32_t* const cb = B.cnt + sslot_u * kStride + (L.jj >> 2) + 8u * (L.jj & 3u) * kSub;
-
-#ifndef BP_EXP_KMAX
-#define BP_EXP_KMAX 8
-#endif
-#pragma unroll
-  for (int k = 0; k < BP_EXP_KMAX; k++) {
-    const uint32_t nsh = (k == 0 ? (sw << 2) : (sw >> (4 * k - 2))) & 0x3cu;
-    // Seq8ToEnumTable (pileup/common.go:66) x2: nibble 1,2,4,8 -> 0,2,4,6; others 8 (X);
-    // and the plane a base failing the quality rule goes to: X stays X (always counted,
-    // pileup.go:227), others go to the depth-only plane 10.
-    const uint32_t c2 = (uint32_t)(0x8888888688848208ull >> nsh) & 15u;
-    const uint32_t cf = (uint32_t)(0x8888888a888a8aa8ull >> nsh) & 15u;
-    uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
-    if constexpr (CLIP) q = clipped_qual(q, b0 + k, (int32_t)lseq, clip);
-    uint32_t val = (mask >> k) & 1u;
-    uint32_t code = q >= minq ? c2 : cf;  // addBase (pileup.go:223-231)
-    if constexpr (STITCH) {
-      if (mate_idx >= 0 && val) {
-        const int32_t rp = Pw + k + g0;
-        const int32_t mi = read_index_at(mc, P.blob, rp);
-        if (mi >= 0) {
-          // both reads of the pair cover this position (pileup.go:409-430): Depth++ once,
-          // handled by the read that found its mate
-          if (!second) {
-            val = 0;
-          } else {
-            const uint8_t* mb = P.blob + (uint64_t)mc.blob * 8;
-            const uint32_t mcig = ((mc.n_cigar + 1u) & ~1u) * 4;
-            const uint32_t mU = ((uint32_t)mc.l_seq + 7) >> 3;
-            uint32_t mq = mb[mcig + mi];
-            const uint32_t mbyte = mb[mcig + 8 * mU + (mi >> 1)];
-            const uint32_t mnib = (mi & 1) ? (mbyte >> 4) : (mbyte & 15u);
-            if constexpr (CLIP) mq = clipped_qual(mq, mi, (int32_t)mc.l_seq, clip);
-            if (mnib * 4 == nsh) {
-              if (q >= 96u || mq >= 96u) {
-                // qualPassTable index out of range: a Go runtime panic in the reference
-                atomicMin(&P.err->read, myrec);
-                val = 0;
-              } else {
-                code = mq >= (uint32_t)P.qthr[q] ? c2 : cf;
-              }
-            } else {
-              code = 8u;
-            }
-          }
-        }
-      }
-    }
-    atomicAdd(cb + code * kStride + k * kSub, val);
-  }
-}
-
 template <bool STITCH, bool CLIP, bool MINQ0>
 __device__ __forceinline__ void unit(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
-                                     const UnitLoad<STITCH || !MINQ0>& L, uint32_t wlen, int32_t g0) {
-  if constexpr (STITCH) {
-    const uint32_t act = (L.meta & 0x10000u);
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      Group8 g;
-      g.q0 = L.qd[2 * m]; g.q1 = L.qd[2 * m + 1]; g.q2 = L.qd[2 * m + 2];
-      g.s0 = L.sd[m]; g.s1 = L.sd[m + 1];
-      g.seg = L.seg | act;
-      g.jj = 4u * (L.meta & 0x3fu) + m;
-      g.sslot = (L.meta >> 11) & 1u;
-      process_unit<true, CLIP>(P, B, g, wlen, g0);
-    }
-  } else {
-    process_unit_plain<CLIP, MINQ0>(P, B, L);
-  }
+                                     const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t wlen, int32_t g0) {
+  (void)wlen; (void)g0;
+  process_unit_plain<STITCH, CLIP, MINQ0 && !STITCH>(P, B, L);
 }
 
 // Advance the CIGAR cursor (c, r, q) = (op index, window position, read index) to the next M
@@ -648,6 +674,9 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
   if (tid == 0) S.n_alloc[0] = S.n_alloc[1] = 0;
+  if constexpr (STITCH) {
+    if (tid < 96) S.ex.qthr[tid] = P.qthr[tid];
+  }
   uint32_t par = 0;  // round parity (block-uniform)
   __syncthreads();
 
@@ -680,6 +709,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     bool have = false, keep = false, prefetched = true, next_issued = false;
     uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, sslot = 0, aux = 0, span = 0;
     uint32_t cg0 = 0, cg1 = 0, cg2 = 0;
+    uint4 minfo = make_uint4(0, 0, 0, 0);
     int32_t rr = 0, qq = 0;
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
 
@@ -713,6 +743,25 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         else keep = keep && (strand != 0 || P.ignore_strand);
         keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
         sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
+        minfo = make_uint4(0, 0, 0, 0);
+        if constexpr (STITCH) {
+          if (keep) {
+            const int32_t m = P.mate[rec];
+            if (m >= 0) {
+              const uint4* mp = (const uint4*)(P.cores + (m >> 1));
+              const uint4 m0 = mp[0], m1 = mp[1];
+              const uint32_t maux = m0.y >> 24;
+              // the pair is counted on the strand of the read that found its mate
+              // (pileup.go:799-802); for the stored read that is the mate's strand
+              if (!(m & 1) && !P.ignore_strand)
+                sslot = (uint32_t)(strand_of((maux & AUX_MATE_SAME) != 0, m0.y & 0xffffu) - 1) & 1u;
+              minfo.x = (uint32_t)((int32_t)m0.x - g0);
+              minfo.y = (m0.z >> 16) | ((maux & AUX_SIMPLE) ? 0x10000u : 0u) | ((uint32_t)(m & 1) << 17) | 0x40000u;
+              minfo.z = m1.x;
+              minfo.w = (m0.w & 0xffffu) | ((m0.z & 0xffffu) << 16);
+            }
+          }
+        }
         c_cur = 0;
         rr = pos - g0;
         qq = 0;
@@ -745,7 +794,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         }
         if (!__any(wantA)) break;
-        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec, par);
+        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec, par, minfo);
         if (wantA) {
           if (!ok) {
             failed = true;
@@ -800,11 +849,11 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       {
         unsigned long long a_issue = 0, a_wait = 0, a_proc = 0;
         for (uint32_t tb = wbase; tb < T; tb += kBlock) {
-          UnitLoad<NEED_Q> L1;
+          UnitLoad<NEED_Q, STITCH> L1;
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t0 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          issue_unit<NEED_Q>(P, S, tb + (tid & 63), T, (T + 63) / 64, L1);
+          issue_unit<NEED_Q, STITCH>(P, S, tb + (tid & 63), T, (T + 63) / 64, L1);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -829,14 +878,14 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // Every thread runs n_it unit slots (block-uniform).  The steady-state loop has no
         // branch in its body, so the compiler's counted vmcnt waits keep kD units' loads in
         // flight; at 30x a window is 2-3 units per thread and the loop body rarely runs.
-        constexpr int kD = NEED_Q ? kDepthQ : kDepth;
+        constexpr int kD = STITCH ? 1 : (NEED_Q ? kDepthQ : kDepth);
         const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
         const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
-        UnitLoad<NEED_Q> L[kD];
+        UnitLoad<NEED_Q, STITCH> L[kD];
         uint32_t t = (uint32_t)tid;
 #pragma unroll
         for (int d = 0; d < kD; d++) {
-          issue_unit<NEED_Q>(P, S, t, T, R, L[d]);
+          issue_unit<NEED_Q, STITCH>(P, S, t, T, R, L[d]);
           t += kBlock;
         }
         uint32_t it = 0;
@@ -844,7 +893,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 #pragma unroll
           for (int d = 0; d < kD; d++) {
             unit<STITCH, CLIP, MINQ0>(P, S, L[d], wlen, g0);
-            issue_unit<NEED_Q>(P, S, t, T, R, L[d]);
+            issue_unit<NEED_Q, STITCH>(P, S, t, T, R, L[d]);
             t += kBlock;
           }
         }

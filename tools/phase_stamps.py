@@ -13,9 +13,12 @@ from bio_amd import _abi, snp, synth  # noqa: E402
 
 _abi.LIB_PATH = os.environ.get("STAMPS_LIB") or os.path.join(ROOT, "bio_amd", "libbiopileup_stamps.so")
 L = int(float(sys.argv[1])) if len(sys.argv) > 1 else 40_000_000
-sb = synth.generate([(0, 0, L - 1000, 30.0)])
+STITCH = bool(os.environ.get("STITCH"))
+MINQ = int(os.environ.get("MINQ", "0"))
+GEN = dict(frac_softclip=0, frac_del=0, frac_ins=0, frac_hardclip=0) if os.environ.get("SIMPLE") else {}
+sb = synth.generate([(0, 0, L - 1000, 30.0)], with_names=STITCH, **GEN)
 rb = sb.to_record_batch()
-job = snp.PileupJob(snp.device_opts(snp.Opts(), "basestrand-tsv"), [L])
+job = snp.PileupJob(snp.device_opts(snp.Opts(Stitch=STITCH, MinBaseQual=MINQ), "basestrand-tsv"), [L])
 job.set_bed({0: [[0, L]]})
 job.submit(rb)
 job.finish()

@@ -108,7 +108,7 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_feat;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_feat, d_items;
   bool per_read_valid = false;
   uint64_t n_feat = 0;
   Staging stage[2];
@@ -651,6 +651,15 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
   return BP_OK;
 }
 
+constexpr int32_t kSliceRecs = 2048;  // records per slice of a deep window
+
+// Upper bound on the extra work items of deep windows: a record is counted in every window its
+// span can reach.
+static int64_t item_capacity(const bp_handle* h) {
+  const int64_t per_rec = (int64_t)h->max_span / window_size() + 2;
+  return per_rec * (h->n_reads / kSliceRecs + 1) + 16;
+}
+
 // Kernel arguments for the handle's resident job.
 static void fill_params(bp_handle* h, KernelParams& P) {
   P.cores = (const ReadCore*)h->d_cores.p;
@@ -667,6 +676,10 @@ static void fill_params(bp_handle* h, KernelParams& P) {
   P.err = (DeviceError*)h->d_err.p;
   P.qthr = (const uint8_t*)h->d_qthr.p;
   P.dbg = nullptr;
+  P.slice_recs = kSliceRecs;
+  P.extra_cap = (int32_t)std::min<int64_t>(item_capacity(h), 0x7fffffff);
+  P.extra_items = (uint4*)((uint8_t*)h->d_items.p + 256);
+  P.n_extra = (uint32_t*)h->d_items.p;
   P.n_reads = h->n_reads;
   P.n_windows = (int32_t)h->windows.size();
   P.max_span = h->max_span;
@@ -702,6 +715,8 @@ int bp_compute(bp_handle* h) {
     if (int rc = ensure(h, h->d_ref_first, (nref + 1) * 8 + 256, 0)) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_ref_first.p, rf.data(), (nref + 1) * 8, hipMemcpyHostToDevice, h->stream));
   }
+  if (int rc = ensure(h, h->d_items, 256 + (size_t)item_capacity(h) * 16, 0)) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_items.p, 0, 256, h->stream));
   DeviceError init{0x7fffffff, ERR_NONE};
   HIP_TRY(h, hipMemcpyAsync(h->d_err.p, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
   KernelParams P{};
@@ -726,6 +741,8 @@ int bp_compute(bp_handle* h) {
   (void)hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[2]);
   h->timing.n_windows = (int64_t)h->windows.size();
   h->timing.n_items = (int64_t)h->windows.size();
+  if (got.kind == ERR_ITEM_OVERFLOW)
+    return fail(h, BP_EDEVICE, "bp_compute: work-item list of deep windows overflowed");
   if (got.read != 0x7fffffff)
     return fail(h, BP_EDATA,
                 "qualPassTable.lookup2: base quality >= 96 in a stitched overlap (record %d); the "
@@ -898,7 +915,7 @@ void bp_destroy(bp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+  for (DevBuf* b : {&h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {

@@ -1,5 +1,6 @@
 // pileup_device.h -- data layout shared by the host code and the gfx950 kernels.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace bp {
@@ -63,7 +64,7 @@ struct DeviceError {
   int32_t read;  // smallest record index with a data error, or 0x7fffffff
   int32_t kind;
 };
-enum { ERR_NONE = 0, ERR_QUAL_RANGE = 1 };
+enum { ERR_NONE = 0, ERR_QUAL_RANGE = 1, ERR_ITEM_OVERFLOW = 2 };
 
 struct KernelParams {
   const ReadCore* cores;
@@ -79,6 +80,13 @@ struct KernelParams {
   uint32_t* rows;             // n_rows * 11
   DeviceError* err;
   const uint8_t* qthr;        // [96] stitch: qthr[q0] = smallest q1 with qualSum[q0][q1] >= minBaseQual (255: none)
+  // Deep windows (more than 2*slice_recs records) are cut into slices of slice_recs records:
+  // the window's own work item keeps the first slice, the plan kernel appends the others
+  // here as (window, first record, end record, 0) and a second launch adds them to the rows.
+  uint4* extra_items;
+  uint32_t* n_extra;          // number of appended items (device counter, reset per compute)
+  int32_t extra_cap;
+  int32_t slice_recs;
   unsigned long long* dbg;    // diagnostic builds only (BP_STAMPS); NULL otherwise
   int64_t n_reads;
   int32_t n_windows;

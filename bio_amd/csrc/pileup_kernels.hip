@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "pileup_device.h"
@@ -48,7 +49,7 @@ namespace bp {
 #ifdef BP_STAMPS
 #define BP_STAMP(i)                                                                      \
   do {                                                                                   \
-    if (P.dbg && (threadIdx.x & 63) == 0)                                                \
+    if (!DEEP && P.dbg && (threadIdx.x & 63) == 0)                                       \
       P.dbg[((uint64_t)item * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
@@ -128,7 +129,24 @@ __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* wi
     if (P.cores[m].pos < win.g1) a = m + 1; else b = m;
   }
   win_r0[w] = (int32_t)r0;
-  win_r1[w] = (int32_t)a;
+  int64_t r1 = a;
+  // a deep window keeps its first slice; the rest become extra work items
+  const int64_t n = r1 - r0, sl = P.slice_recs;
+  if (P.extra_items && n > 2 * sl) {
+    const uint32_t cnt = (uint32_t)((n - sl + sl - 1) / sl);
+    const uint32_t base = atomicAdd(P.n_extra, cnt);
+    for (uint32_t k = 0; k < cnt; k++) {
+      if (base + k >= (uint32_t)P.extra_cap) {
+        P.err->kind = ERR_ITEM_OVERFLOW;
+        break;
+      }
+      const int64_t s0 = r0 + sl * (int64_t)(k + 1);
+      const int64_t s1 = s0 + sl < r1 ? s0 + sl : r1;
+      P.extra_items[base + k] = make_uint4((uint32_t)w, (uint32_t)s0, (uint32_t)s1, 0u);
+    }
+    r1 = r0 + sl;
+  }
+  win_r1[w] = (int32_t)r1;
 }
 
 constexpr int kUnitPos = 32;               // window positions per unit
@@ -655,12 +673,21 @@ __device__ __forceinline__ bool next_m_op(const uint32_t* cg, uint32_t cg0, uint
 // Two barriers per window (after phase 1, after phase 2).  The record cores of window i+1
 // are loaded while window i is in phase 2, so the only exposed memory latency per window is
 // that of the unit loads.
-template <bool STITCH, bool CLIP, bool MINQ0>
+// DEEP = true is the second launch over the extra slices of deep windows: one work item per
+// loop iteration, taken from P.extra_items, flushed with atomic adds on top of the rows the
+// first launch wrote.
+template <bool STITCH, bool CLIP, bool MINQ0, bool DEEP>
 __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParams P) {
   constexpr bool NEED_Q = STITCH || !MINQ0;
   constexpr bool EXTRA = STITCH || CLIP;
   __shared__ BlockSharedT<EXTRA> S;
   const int tid = threadIdx.x;
+  uint32_t n_items = 0;
+  if constexpr (DEEP) {
+    n_items = *P.n_extra;
+    if (n_items > (uint32_t)P.extra_cap) n_items = (uint32_t)P.extra_cap;
+    if (blockIdx.x >= n_items) return;
+  }
 
   // XCD-aware order: workgroups b and b+8 share an XCD (and its L2); give each XCD a
   // contiguous run of windows so records straddling two workgroups are re-read from L2.
@@ -668,9 +695,13 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   const uint32_t xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
   const uint32_t q8 = nwg >> 3, r8 = nwg & 7u;
   const uint32_t blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
-  const uint32_t w_first = blk * kWinPerBlock;
+  uint32_t w_first = blk * kWinPerBlock;
   uint32_t w_last = w_first + kWinPerBlock;
   if (w_last > (uint32_t)P.n_windows) w_last = (uint32_t)P.n_windows;
+  if constexpr (DEEP) {  // here `item` walks the extra items, one block stride apart
+    w_first = blockIdx.x;
+    w_last = n_items;
+  }
 
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
   if (tid == 0) S.n_alloc[0] = S.n_alloc[1] = 0;
@@ -683,12 +714,21 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   // Everything a window needs from global memory before its unit loads is fetched one
   // window ahead (record range two ahead): window descriptor, record range, this thread's
   // first record core.
-  Window n_win = P.windows[w_first];
-  int32_t n_r0 = P.win_r0[w_first], n_r1 = P.win_r1[w_first];
-  int32_t nn_r0 = 0, nn_r1 = 0;
-  if (w_first + 1 < w_last) {
-    nn_r0 = P.win_r0[w_first + 1];
-    nn_r1 = P.win_r1[w_first + 1];
+  Window n_win;
+  int32_t n_r0, n_r1, nn_r0 = 0, nn_r1 = 0;
+  if constexpr (DEEP) {
+    const uint4 it = P.extra_items[w_first];
+    n_win = P.windows[it.x];
+    n_r0 = (int32_t)it.y;
+    n_r1 = (int32_t)it.z;
+  } else {
+    n_win = P.windows[w_first];
+    n_r0 = P.win_r0[w_first];
+    n_r1 = P.win_r1[w_first];
+    if (w_first + 1 < w_last) {
+      nn_r0 = P.win_r0[w_first + 1];
+      nn_r1 = P.win_r1[w_first + 1];
+    }
   }
   uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0;
   if (n_r0 + tid < n_r1) {
@@ -697,7 +737,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     pc1 = cp[1];
   }
 
-  for (uint32_t item = w_first; item < w_last; item++) {
+  for (uint32_t item = w_first; item < w_last; item += DEEP ? gridDim.x : 1u) {
     const Window win = n_win;
     const int32_t r0 = n_r0, r1 = n_r1;
     const int32_t g0 = win.g0, g1 = win.g1;
@@ -820,7 +860,19 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       // ---- prefetch for the next window(s)
       if (!next_issued) {
         next_issued = true;
-        if (item + 1 < w_last) {
+        if constexpr (DEEP) {
+          if (item + gridDim.x < w_last) {
+            const uint4 it = P.extra_items[item + gridDim.x];
+            n_win = P.windows[it.x];
+            n_r0 = (int32_t)it.y;
+            n_r1 = (int32_t)it.z;
+            if (n_r0 + tid < n_r1) {
+              const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
+              nc0 = cp[0];
+              nc1 = cp[1];
+            }
+          }
+        } else if (item + 1 < w_last) {
           n_r0 = nn_r0;
           n_r1 = nn_r1;
           n_win = P.windows[item + 1];
@@ -949,12 +1001,21 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 #ifdef BP_EXP_NOFLUSH
       if (d != 0x7fffffffu) continue;
 #endif
-      u32x4a o0 = {d, v[0], v[1], v[2]};
-      u32x4a o1 = {v[3], v[4], v[5], v[6]};
-      u32x3a o2 = {v[7], v[8], v[9]};
-      *(u32x4a*)(out) = o0;
-      *(u32x4a*)(out + 4) = o1;
-      *(u32x3a*)(out + 8) = o2;
+      if constexpr (DEEP) {
+        if (d != 0) {
+          atomicAdd(out, d);
+#pragma unroll
+          for (int c = 0; c < 10; c++)
+            if (v[c]) atomicAdd(out + 1 + c, v[c]);
+        }
+      } else {
+        u32x4a o0 = {d, v[0], v[1], v[2]};
+        u32x4a o1 = {v[3], v[4], v[5], v[6]};
+        u32x3a o2 = {v[7], v[8], v[9]};
+        *(u32x4a*)(out) = o0;
+        *(u32x4a*)(out + 4) = o1;
+        *(u32x3a*)(out + 8) = o2;
+      }
     }
     BP_STAMP(6);
     pc0 = nc0;
@@ -1128,20 +1189,27 @@ void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s)
   hipLaunchKernelGGL(plan_windows_kernel, dim3(blocks), dim3(threads), 0, s, P, r0, r1);
 }
 
-void launch_pileup(const KernelParams& P, hipStream_t s) {
-  if (P.n_windows == 0) return;
-  const dim3 g((P.n_windows + kWinPerBlock - 1) / kWinPerBlock), b(kBlock);
+template <bool DEEP>
+static void launch_pileup_variant(const KernelParams& P, dim3 g, hipStream_t s) {
+  const dim3 b(kBlock);
   const bool clip = P.clip > 0;
   if (P.stitch) {
-    if (clip) hipLaunchKernelGGL((pileup_kernel<true, true, false>), g, b, 0, s, P);
-    else hipLaunchKernelGGL((pileup_kernel<true, false, false>), g, b, 0, s, P);
+    if (clip) hipLaunchKernelGGL((pileup_kernel<true, true, false, DEEP>), g, b, 0, s, P);
+    else hipLaunchKernelGGL((pileup_kernel<true, false, false, DEEP>), g, b, 0, s, P);
   } else if (P.min_base_qual == 0) {
     // every base passes the quality rule, clipped or not: the quals are never read
-    hipLaunchKernelGGL((pileup_kernel<false, false, true>), g, b, 0, s, P);
+    hipLaunchKernelGGL((pileup_kernel<false, false, true, DEEP>), g, b, 0, s, P);
   } else {
-    if (clip) hipLaunchKernelGGL((pileup_kernel<false, true, false>), g, b, 0, s, P);
-    else hipLaunchKernelGGL((pileup_kernel<false, false, false>), g, b, 0, s, P);
+    if (clip) hipLaunchKernelGGL((pileup_kernel<false, true, false, DEEP>), g, b, 0, s, P);
+    else hipLaunchKernelGGL((pileup_kernel<false, false, false, DEEP>), g, b, 0, s, P);
   }
+}
+
+void launch_pileup(const KernelParams& P, hipStream_t s) {
+  if (P.n_windows == 0) return;
+  launch_pileup_variant<false>(P, dim3((P.n_windows + kWinPerBlock - 1) / kWinPerBlock), s);
+  // extra slices of deep windows; blocks beyond the item count (read on the device) exit at once
+  if (P.extra_items) launch_pileup_variant<true>(P, dim3((unsigned)std::min(P.extra_cap, 2048)), s);
 }
 
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s) {

@@ -116,8 +116,11 @@ def test_c1_region_mode_no_halo():
     assert_same(got, want, "region")
 
 
-def test_c4_shape_deep_panel_stitched():
-    """BASELINE config 4 shape (scaled): 200-bp targets, deep, overlapping 2x150 mates."""
+@pytest.mark.parametrize("mode", ["stitch", "plain", "minq_clip"])
+def test_c4_shape_deep_panel(mode):
+    """BASELINE config 4 shape (scaled): 200-bp targets, deep, overlapping 2x150 mates.  Each
+    window holds ~4,700 records: more than two slices, so the deep-window path (extra work
+    items, atomic flush) is what is checked here."""
     rng = random.Random(4)
     targets, p = [], 10_000
     for _ in range(12):
@@ -125,7 +128,8 @@ def test_c4_shape_deep_panel_stitched():
         p += 200 + rng.randint(50, 3000)
     bed = {0: targets}
     regions = [(0, s, e, 2000.0) for s, e in targets]
-    opts = O.make_opts(stitch=1, min_base_qual=20, mapq=60)
+    opts = O.make_opts(mapq=60, **dict(stitch=dict(stitch=1, min_base_qual=20), plain=dict(),
+                                       minq_clip=dict(min_base_qual=25, clip=7))[mode])
     got, want, sb = _synth_case(regions, bed, [p + 10_000], opts, with_names=True,
                                 insert_mean=170.0, insert_sd=20.0, insert_min=100, insert_max=300)
     assert_same(got, want, "panel")

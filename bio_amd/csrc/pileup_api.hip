@@ -94,6 +94,8 @@ struct bp_handle {
   int64_t algo_in_bytes = 0;
   uint64_t last_key = 0;
   int32_t max_span = 1;
+  std::vector<int32_t> coarse_pos; // pos of every kCoarse-th record, for the plan kernel
+  size_t coarse_uploaded = 0;
   std::vector<int64_t> ref_first;  // [n_ref+1] first record index of each reference
   std::vector<int64_t> ref_first_closed;  // copy uploaded by bp_compute (kept alive for the async copy)
   int32_t cur_ref = 0;             // references < cur_ref are complete
@@ -108,7 +110,7 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_feat, d_items;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_feat, d_items, d_coarse;
   bool per_read_valid = false;
   uint64_t n_feat = 0;
   Staging stage[2];
@@ -376,6 +378,7 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1,
     spans[(size_t)(i - i0)] = span;
     simple[(size_t)(i - i0)] = simp ? 1 : 0;
     const int64_t gidx = h->n_reads + (i - i0);
+    if ((gidx & (kCoarse - 1)) == 0) h->coarse_pos.push_back(pos);
     if (o.stitch) h->mate[(size_t)gidx] = -1;
     // read-level filters (pileup.go:691, :717-729)
     const uint32_t flags = b->flags[i];
@@ -669,6 +672,7 @@ static void fill_params(bp_handle* h, KernelParams& P) {
   P.win_r0 = (const int32_t*)h->d_r0.p;
   P.win_r1 = (const int32_t*)h->d_r1.p;
   P.ref_first = (const int64_t*)h->d_ref_first.p;
+  P.coarse_pos = (const int32_t*)h->d_coarse.p;
   P.iv_start = (const int32_t*)h->d_iv_start.p;
   P.iv_end = (const int32_t*)h->d_iv_end.p;
   P.iv_row = (const int64_t*)h->d_iv_row.p;
@@ -714,6 +718,12 @@ int bp_compute(bp_handle* h) {
     for (size_t r = (size_t)h->cur_ref + 1; r <= nref; r++) rf[r] = h->n_reads;
     if (int rc = ensure(h, h->d_ref_first, (nref + 1) * 8 + 256, 0)) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_ref_first.p, rf.data(), (nref + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  }
+  if (int rc = ensure(h, h->d_coarse, h->coarse_pos.size() * 4 + 256, h->coarse_uploaded * 4)) return rc;
+  if (h->coarse_uploaded < h->coarse_pos.size()) {
+    HIP_TRY(h, hipMemcpyAsync((int32_t*)h->d_coarse.p + h->coarse_uploaded, h->coarse_pos.data() + h->coarse_uploaded,
+                              (h->coarse_pos.size() - h->coarse_uploaded) * 4, hipMemcpyHostToDevice, h->stream));
+    h->coarse_uploaded = h->coarse_pos.size();
   }
   if (int rc = ensure(h, h->d_items, 256 + (size_t)item_capacity(h) * 16, 0)) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_items.p, 0, 256, h->stream));
@@ -915,7 +925,7 @@ void bp_destroy(bp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {

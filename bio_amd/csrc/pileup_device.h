@@ -60,6 +60,8 @@ static_assert(sizeof(Window) == 40, "Window must be 40 bytes");
 // second = 1 for the read that found its mate in the table (readPair[0], firstread.go:187).
 typedef int32_t MateRef;
 
+constexpr int kCoarse = 1024;  // stride of the coarse position index the plan kernel searches first
+
 struct DeviceError {
   int32_t read;  // smallest record index with a data error, or 0x7fffffff
   int32_t kind;
@@ -74,6 +76,7 @@ struct KernelParams {
   const int32_t* win_r0;      // per window: first record that may overlap it
   const int32_t* win_r1;      // per window: one past the last record starting before g1
   const int64_t* ref_first;   // [n_ref+1] index of the first record of each reference
+  const int32_t* coarse_pos;  // pos of every kCoarse-th record (index k <-> record k*kCoarse)
   const int32_t* iv_start;
   const int32_t* iv_end;
   const int64_t* iv_row;

@@ -108,6 +108,27 @@ __device__ __forceinline__ int strand_of(bool mate_same_ref, uint32_t flags) {
   return 0;
 }
 
+// First record index in [lo, hi) whose pos is >= x (records of one reference are sorted by
+// pos).  The coarse index (every kCoarse-th record, a few hundred KB, cache-resident) narrows
+// the range to kCoarse records before the 32-byte cores are touched.
+__device__ int64_t first_at_or_after(const KernelParams& P, int64_t lo, int64_t hi, int64_t x) {
+  int64_t cl = (lo + kCoarse - 1) / kCoarse, ch = (hi + kCoarse - 1) / kCoarse;
+  const int64_t c0 = cl;
+  while (cl < ch) {
+    const int64_t m = (cl + ch) >> 1;
+    if ((int64_t)P.coarse_pos[m] < x) cl = m + 1; else ch = m;
+  }
+  // record cl*kCoarse is the first sampled one at or after x (or there is none)
+  int64_t a = cl > c0 ? (cl - 1) * kCoarse + 1 : lo;
+  int64_t b = cl * kCoarse < hi ? cl * kCoarse : hi;
+  if (a > b) a = b;
+  while (a < b) {
+    const int64_t m = (a + b) >> 1;
+    if ((int64_t)P.cores[m].pos < x) a = m + 1; else b = m;
+  }
+  return a;
+}
+
 __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* win_r1) {
   int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= P.n_windows) return;
@@ -117,17 +138,8 @@ __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* wi
   // first record that can reach g0: pos >= g0 - max_span + 1
   int64_t lo_pos = (int64_t)win.g0 - P.max_span + 1;
   if (lo_pos < 0) lo_pos = 0;
-  int64_t a = lo, b = hi;
-  while (a < b) {
-    const int64_t m = (a + b) >> 1;
-    if ((int64_t)P.cores[m].pos < lo_pos) a = m + 1; else b = m;
-  }
-  const int64_t r0 = a;
-  b = hi;
-  while (a < b) {
-    const int64_t m = (a + b) >> 1;
-    if (P.cores[m].pos < win.g1) a = m + 1; else b = m;
-  }
+  const int64_t r0 = first_at_or_after(P, lo, hi, lo_pos);
+  const int64_t a = first_at_or_after(P, r0, hi, win.g1);
   win_r0[w] = (int32_t)r0;
   int64_t r1 = a;
   // a deep window keeps its first slice; the rest become extra work items
@@ -574,11 +586,7 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
           }
           cw = (cw & ~(0xfu << (4 * k))) | (code << (4 * k));
         };
-#ifdef BP_EXP_NODECIDE
-        const uint32_t ovg = 0;
-#else
         const uint32_t ovg = ((ov32 & vmask) >> (8 * m)) & 0xffu;
-#endif
         if (ovg) {
           const uint32_t mqlo = __builtin_amdgcn_alignbyte(L.mq[2 * m + 1], L.mq[2 * m], L.msh & 3u);
           const uint32_t mqhi = __builtin_amdgcn_alignbyte(L.mq[2 * m + 2], L.mq[2 * m + 1], L.msh & 3u);
@@ -592,12 +600,7 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
               decide(k, (msw >> (4 * k)) & 15u, ((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu, mi0 + k);
         }
         const int32_t mrel = (int32_t)mi4.x, mspan = (int32_t)(mi4.y & 0xffffu);
-#ifdef BP_EXP_NOSLOW
-        if (false && Pw + 8 > mrel
-#else
-        if (mslow && Pw + 8 > mrel
-#endif
- && Pw < mrel + mspan && ((vmask >> (8 * m)) & 0xffu)) {
+        if (mslow && Pw + 8 > mrel && Pw < mrel + mspan && ((vmask >> (8 * m)) & 0xffu)) {
           const bool second = (mi4.y & 0x20000u) != 0;
           const uint8_t* mb = P.blob + (uint64_t)mi4.z * 8;
           const uint32_t mcig = ((((mi4.w >> 16)) + 1u) & ~1u) * 4;
@@ -998,9 +1001,6 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         R = P.iv_row[a] + (gp - is);
       }
       uint32_t* out = P.rows + R * 11;
-#ifdef BP_EXP_NOFLUSH
-      if (d != 0x7fffffffu) continue;
-#endif
       if constexpr (DEEP) {
         if (d != 0) {
           atomicAdd(out, d);

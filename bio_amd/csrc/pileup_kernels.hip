@@ -186,11 +186,14 @@ struct SegExtra {
   uint32_t s_lenq0[kSegCap];    // length | read offset << 16
   uint32_t s_lseqnc[kSegCap];   // l_seq | n_cigar << 16
   int32_t s_rec[kSegCap];       // record index
-  // the record's mate (stitch): x = mate start relative to the window start, y = span |
-  // single-M-op << 16 | this record is the one that found its mate << 17 | has a mate << 18,
-  // z = mate payload offset, w = mate l_seq | n_cigar << 16
+  // the M op of the record's mate that this segment can overlap (stitch; phase 1 cuts a
+  // segment wherever the mate's next M op starts, so there is at most one): x = its start
+  // relative to the window start, y = its length | this record is the one that found its
+  // mate << 17 | has a mate << 18, z = mate payload offset, w = mate l_seq | n_cigar << 16;
+  // s_mq0 = read index of its first base
   uint4 s_mate[kSegCap];
-  uint8_t qthr[96];             // copy of KernelParams::qthr
+  uint16_t s_mq0[kSegCap];
+  uint8_t qthr[96];             // KernelParams::qthr, "never" clamped to 96
 };
 struct NoExtra {};
 
@@ -302,7 +305,8 @@ __device__ __forceinline__ bool seg_extent(const SegIn& g, uint32_t wlen, int32_
 template <bool EXTRA>
 __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, uint32_t us, const SegIn& g,
                                           int32_t s1, int32_t e1, uint32_t jlo, uint32_t U, uint32_t blob,
-                                          uint32_t lseqnc, uint32_t sslot, int32_t rec, uint4 minfo) {
+                                          uint32_t lseqnc, uint32_t sslot, int32_t rec, uint4 minfo,
+                                          uint32_t mq0) {
   // byte offsets inside the record payload [cigar padded to even][qual 8*Ur][seq 4*Ur]
   const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
   const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
@@ -325,6 +329,7 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
     S.ex.s_lseqnc[idx] = lseqnc;
     S.ex.s_rec[idx] = rec;
     S.ex.s_mate[idx] = minfo;
+    S.ex.s_mq0[idx] = (uint16_t)mq0;
   }
   for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
 }
@@ -337,7 +342,8 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
 template <bool EXTRA>
 __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
                                           const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
-                                          uint32_t sslot, int32_t rec, uint32_t par, uint4 minfo) {
+                                          uint32_t sslot, int32_t rec, uint32_t par, uint4 miA, uint32_t mq0A,
+                                          uint4 miB, uint32_t mq0B) {
   int32_t s1A, e1A, s1B, e1B;
   uint32_t jloA, UA, jloB, UB;
   const bool realA = seg_extent(A, wlen, s1A, e1A, jloA, UA) && wantA;  // clipped-away segments need no slot
@@ -359,8 +365,8 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
   const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
   const bool ok = idx + nseg <= (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
   if (ok) {
-    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, sslot, rec, minfo);
-    if (realB) write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, sslot, rec, minfo);
+    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, sslot, rec, miA, mq0A);
+    if (realB) write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, sslot, rec, miB, mq0B);
   } else {
     for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
   }
@@ -447,18 +453,19 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
     // with the same wide loads as its own.
     const uint4 mi4 = S.ex.s_mate[s];
     const bool mhas = in && (mi4.y & 0x40000u) != 0;
-    const bool msimple = (mi4.y & 0x10000u) != 0, second = (mi4.y & 0x20000u) != 0;
-    const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x;  // mate read index of the unit's position 0
+    const bool second = (mi4.y & 0x20000u) != 0;
+    // mate read index of the unit's position 0
+    const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x + (int32_t)S.ex.s_mq0[s];
     uint32_t ov = 0;
-    if (mhas && msimple) {
-      const int32_t lo = -mi0, hi = lo + (int32_t)(mi4.y & 0xffffu);
+    if (mhas) {
+      const int32_t lo = (int32_t)mi4.x - (int32_t)(32u * jj), hi = lo + (int32_t)(mi4.y & 0xffffu);
       const int32_t l2 = lo > 0 ? lo : 0, h2 = hi < 32 ? hi : 32;
       if (h2 > l2) ov = (h2 - l2 >= 32 ? 0xffffffffu : ((1u << (h2 - l2)) - 1u) << l2);
       if (!second) { L.mask &= ~ov; ov = 0; }
     }
     ov &= L.mask;
     L.ov32 = ov;
-    L.meta |= (mhas && !msimple ? 0x20000u : 0u) | (second ? 0x40000u : 0u);
+    L.meta |= second ? 0x40000u : 0u;
     const uint32_t mlseqnc = mi4.w;
     const int32_t mcig = (int32_t)((((mlseqnc >> 16) + 1u) & ~1u) * 4);
     const int32_t qo = mcig + mi0;  // >= -23: the payload buffer starts with a pad
@@ -496,16 +503,9 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
   static_assert(!(STITCH && MINQ0), "the stitched path always reads the quals");
   constexpr uint32_t M1 = 0x11111111u;
   const uint32_t meta = L.meta;
-  // mate of the record (prepared in phase 1)
-  uint4 mi4 = make_uint4(0, 0, 0, 0);
   const uint32_t jj = meta & 0x3fu;
   uint32_t vmask = L.mask;  // positions still to be counted
   const uint32_t ov32 = L.ov32;
-  bool mslow = false;  // mate with a longer CIGAR: per-base walk
-  if constexpr (STITCH) {
-    mi4 = B.ex.s_mate[L.seg];
-    mslow = (meta & 0x20000u) != 0;
-  }
   const uint32_t* const x = L.sd;  // base k of a dword at bits 4k (the packer stores it that way)
   const uint32_t nsh = (meta >> 4) & 0x1cu;  // 4 * nibble shift
   const uint32_t cbase = (jj + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
@@ -557,64 +557,86 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
       const uint32_t cpass = cw;
       cw = (cw & pn15) | (cf & ~pn15);
       if constexpr (STITCH) {
-        const int32_t Pw = (int32_t)((4 * jj + m) * 8);
-        // own clipped quals are needed again below
-        int32_t b0 = 0, lseq = 0;
-        if constexpr (CLIP) {
-          const uint32_t sg = L.seg;
-          b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + (Pw - B.ex.s_ref[sg]);
-          lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
-        }
-        const uint32_t mls = mi4.w & 0xffffu;
-        // decide one position both reads cover (pileup.go:409-430), given the mate's base
-        // (BAM code) and quality there
-        auto decide = [&](int k, uint32_t mnib, uint32_t mq, int32_t mi) {
-          uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
-          if constexpr (CLIP) {
-            q = clipped_qual(q, b0 + k, lseq, P.clip);
-            mq = clipped_qual(mq, mi, (int32_t)mls, P.clip);
-          }
-          uint32_t code = 4u;  // the reads disagree: X
-          if (mnib == ((sw >> (4 * k)) & 15u)) {
-            if (q >= 96u || mq >= 96u) {
-              // qualPassTable index out of range: a Go runtime panic in the reference
-              atomicMin(&P.err->read, B.ex.s_rec[L.seg]);
-              vmask &= ~(1u << (8 * m + k));
-              return;
-            }
-            code = ((mq >= (uint32_t)B.ex.qthr[q] ? cpass : cf) >> (4 * k)) & 7u;
-          }
-          cw = (cw & ~(0xfu << (4 * k))) | (code << (4 * k));
-        };
+        // positions of this group that the mate covers too (pileup.go:409-430); only the
+        // record that found its mate has any (the other one dropped them at issue time)
         const uint32_t ovg = ((ov32 & vmask) >> (8 * m)) & 0xffu;
         if (ovg) {
           const uint32_t mqlo = __builtin_amdgcn_alignbyte(L.mq[2 * m + 1], L.mq[2 * m], L.msh & 3u);
           const uint32_t mqhi = __builtin_amdgcn_alignbyte(L.mq[2 * m + 2], L.mq[2 * m + 1], L.msh & 3u);
           const uint32_t msw = __builtin_amdgcn_alignbit(L.ms[m + 1], L.ms[m], (L.msh >> 2) & 0x1cu);
-          const int32_t mi0 = Pw - (int32_t)mi4.x;
-          // (rare, so one rolled copy: unrolling this and the loop below bloated the kernel
-          // past the instruction cache and cost 4x)
-#pragma unroll 1
-          for (int k = 0; k < 8; k++)
-            if ((ovg >> k) & 1u)
-              decide(k, (msw >> (4 * k)) & 15u, ((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu, mi0 + k);
-        }
-        const int32_t mrel = (int32_t)mi4.x, mspan = (int32_t)(mi4.y & 0xffffu);
-        if (mslow && Pw + 8 > mrel && Pw < mrel + mspan && ((vmask >> (8 * m)) & 0xffu)) {
-          const bool second = (mi4.y & 0x20000u) != 0;
-          const uint8_t* mb = P.blob + (uint64_t)mi4.z * 8;
-          const uint32_t mcig = ((((mi4.w >> 16)) + 1u) & ~1u) * 4;
-#pragma unroll 1
-          for (int k = 0; k < 8; k++) {
-            if (!((vmask >> (8 * m + k)) & 1u)) continue;
-            const int32_t mi = read_index_rel(mrel, mi4.w >> 16, mb, Pw + k);
-            if (mi < 0) continue;
-            if (!second) {
-              vmask &= ~(1u << (8 * m + k));
-              continue;
+          // nibble k of dn != 0 <=> the reads disagree at position k
+          const uint32_t dn = msw ^ sw;
+          const uint32_t eqn = ~(dn | (dn >> 1) | (dn >> 2) | (dn >> 3)) & M1;
+          // 8 overlap bits -> one flag per nibble
+          uint32_t ovn = (ovg | (ovg << 12)) & 0x000f000fu;
+          ovn = (ovn | (ovn << 6)) & 0x03030303u;
+          ovn = (ovn | (ovn << 3)) & M1;
+          bool fast = !CLIP;
+          if constexpr (!CLIP) {
+            // a qual >= 96 at an agreeing position indexes qualPassTable out of range (a Go
+            // runtime panic in the reference): those groups take the per-base loop below
+            uint32_t blo = ((((qlo & 0x7f7f7f7fu) + 0x20202020u) | qlo) | (((mqlo & 0x7f7f7f7fu) + 0x20202020u) | mqlo)) & H;
+            uint32_t bhi = ((((qhi & 0x7f7f7f7fu) + 0x20202020u) | qhi) | (((mqhi & 0x7f7f7f7fu) + 0x20202020u) | mqhi)) & H;
+            blo = (blo | (blo >> 4)) & 0x08800880u;
+            blo = (blo | (blo >> 8)) & 0x00088880u;
+            bhi = (bhi | (bhi >> 4)) & 0x08800880u;
+            bhi = (bhi | (bhi >> 8)) & 0x00088880u;
+            fast = ((((blo >> 7) | (bhi << 9)) & eqn & ovn) == 0);
+          }
+          if (fast) {
+            // the pair passes iff mate qual >= qthr[own qual] (qualSumTable row, qual.go:35-77):
+            // 8 byte lookups, then the same byte compare as the single-read rule
+            const uint8_t* const qt = B.ex.qthr;
+            const uint32_t tlo = (uint32_t)qt[qlo & 0xffu] | ((uint32_t)qt[(qlo >> 8) & 0xffu] << 8) |
+                                 ((uint32_t)qt[(qlo >> 16) & 0xffu] << 16) | ((uint32_t)qt[qlo >> 24] << 24);
+            const uint32_t thi = (uint32_t)qt[qhi & 0xffu] | ((uint32_t)qt[(qhi >> 8) & 0xffu] << 8) |
+                                 ((uint32_t)qt[(qhi >> 16) & 0xffu] << 16) | ((uint32_t)qt[qhi >> 24] << 24);
+            // (thresholds <= 96; the mask keeps a stray lookup of a qual >= 96 at a position that
+            // does not matter from borrowing into its neighbour)
+            uint32_t plo = ((mqlo | H) - (tlo & 0x7f7f7f7fu)) & H;
+            uint32_t phi = ((mqhi | H) - (thi & 0x7f7f7f7fu)) & H;
+            plo = (plo | (plo >> 4)) & 0x08800880u;
+            plo = (plo | (plo >> 8)) & 0x00088880u;
+            phi = (phi | (phi >> 4)) & 0x08800880u;
+            phi = (phi | (phi >> 8)) & 0x00088880u;
+            const uint32_t p2 = (plo >> 7) | (phi << 9);
+            const uint32_t p15 = (p2 << 4) - p2, eq15 = (eqn << 4) - eqn, ov15 = (ovn << 4) - ovn;
+            // agree: the base if the pair passes, else depth only (X stays X); disagree: X
+            const uint32_t both = (eq15 & ((cpass & p15) | (cf & ~p15))) | (~eq15 & 0x44444444u);
+            cw = (cw & ~ov15) | (both & ov15);
+          } else {
+            const int32_t Pw = (int32_t)((4 * jj + m) * 8);
+            const uint32_t sg = L.seg;
+            int32_t b0 = 0, lseq = 0;
+            if constexpr (CLIP) {  // own clipped quals are needed again
+              b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + (Pw - B.ex.s_ref[sg]);
+              lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
             }
-            const uint32_t mbyte = mb[mcig + 8 * ((mls + 7) >> 3) + (mi >> 1)];
-            decide(k, (mi & 1) ? (mbyte >> 4) : (mbyte & 15u), mb[mcig + mi], mi);
+            const uint4 mi4 = B.ex.s_mate[sg];
+            const int32_t mls = (int32_t)(mi4.w & 0xffffu);
+            const int32_t mi0 = Pw - (int32_t)mi4.x + (int32_t)B.ex.s_mq0[sg];
+            // (rare, so one rolled copy: unrolled it bloated the kernel past the instruction
+            // cache and cost 4x)
+#pragma unroll 1
+            for (int k = 0; k < 8; k++) {
+              if (!((ovg >> k) & 1u)) continue;
+              uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
+              uint32_t mq = ((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu;
+              if constexpr (CLIP) {
+                q = clipped_qual(q, b0 + k, lseq, P.clip);
+                mq = clipped_qual(mq, mi0 + k, mls, P.clip);
+              }
+              uint32_t code = 4u;  // the reads disagree: X
+              if ((eqn >> (4 * k)) & 1u) {
+                if (q >= 96u || mq >= 96u) {
+                  atomicMin(&P.err->read, B.ex.s_rec[sg]);
+                  vmask &= ~(1u << (8 * m + k));
+                  continue;
+                }
+                code = ((mq >= (uint32_t)B.ex.qthr[q] ? cpass : cf) >> (4 * k)) & 7u;
+              }
+              cw = (cw & ~(0xfu << (4 * k))) | (code << (4 * k));
+            }
           }
         }
       }
@@ -669,6 +691,46 @@ __device__ __forceinline__ bool next_m_op(const uint32_t* cg, uint32_t cg0, uint
   return false;
 }
 
+// Stitching, mate with more than one CIGAR op: the next piece of the record's M ops, cut so
+// that at most one M op of the mate overlaps it (a piece ends where the mate's following M op
+// starts).  (rs, rl, rq) = the part of the current own M op not handed out yet; the mate's
+// CIGAR (mn ops at mcg, first base at window position mrel) is walked again for every piece:
+// such mates are few and their CIGARs short.  (ms, ml, mq0) = the mate M op for this piece
+// (ml = 0: none).
+__device__ __forceinline__ bool next_piece(const uint32_t* cg, uint32_t cg0, uint32_t cg1, uint32_t cg2,
+                                           uint32_t n_cigar, uint32_t wlen, uint32_t& c, int32_t& r, int32_t& q,
+                                           int32_t& rs, int32_t& rl, int32_t& rq, const uint32_t* mcg,
+                                           uint32_t mn, int32_t mrel, int32_t& sref, int32_t& slen,
+                                           int32_t& sq0, int32_t& ms, int32_t& ml, int32_t& mq0) {
+  if (rl == 0 && !next_m_op(cg, cg0, cg1, cg2, n_cigar, wlen, c, r, q, rs, rl, rq)) return false;
+  int32_t mr = mrel, mq = 0, nxt = 0x7fffffff;
+  bool found = false;
+  ms = 0; ml = 0; mq0 = 0;
+  for (uint32_t k = 0; k < mn; k++) {
+    const uint32_t cop = mcg[k];
+    const uint32_t op = cop & 15u;
+    const int32_t len = (int32_t)(cop >> 4);
+    if (op == 0) {
+      if (found) { nxt = mr; break; }
+      if (mr + len > rs) { found = true; ms = mr; ml = len; mq0 = mq; }
+      mr += len;
+      mq += len;
+    } else {
+      mq += (op == 1 || op == 4) ? len : 0;
+      mr += (op == 2 || op == 3) ? len : 0;
+      if (op > 5) break;
+    }
+  }
+  const int32_t e = rs + rl, cut = nxt < e ? nxt : e;  // nxt > rs: it lies past an M op that ends after rs
+  sref = rs;
+  slen = cut - rs;
+  sq0 = rq;
+  rq += slen;
+  rs = cut;
+  rl = cut < (int32_t)wlen ? e - cut : 0;
+  return true;
+}
+
 // Workgroup = kWinPerBlock consecutive windows, processed one after the other:
 //   phase 1  thread = record: read filters, CIGAR -> M-segments clipped to the window
 //   phase 2  thread = unit:   counts into the LDS planes
@@ -709,7 +771,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
   if (tid == 0) S.n_alloc[0] = S.n_alloc[1] = 0;
   if constexpr (STITCH) {
-    if (tid < 96) S.ex.qthr[tid] = P.qthr[tid];
+    if (tid < 96) S.ex.qthr[tid] = P.qthr[tid] < 96 ? P.qthr[tid] : (uint8_t)96;
   }
   uint32_t par = 0;  // round parity (block-uniform)
   __syncthreads();
@@ -754,6 +816,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     uint32_t cg0 = 0, cg1 = 0, cg2 = 0;
     uint4 minfo = make_uint4(0, 0, 0, 0);
     int32_t rr = 0, qq = 0;
+    int32_t rem_s = 0, rem_l = 0, rem_q = 0;  // stitch: rest of the M op being cut into pieces
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
 
     for (;;) {
@@ -799,7 +862,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
               if (!(m & 1) && !P.ignore_strand)
                 sslot = (uint32_t)(strand_of((maux & AUX_MATE_SAME) != 0, m0.y & 0xffffu) - 1) & 1u;
               minfo.x = (uint32_t)((int32_t)m0.x - g0);
-              minfo.y = (m0.z >> 16) | ((maux & AUX_SIMPLE) ? 0x10000u : 0u) | ((uint32_t)(m & 1) << 17) | 0x40000u;
+              minfo.y = (m0.z >> 16) | ((maux & AUX_SIMPLE) ? 0x10000u : 0u) | ((uint32_t)(m & 1) << 17) | 0x40000u;  // bit 16: one M op
               minfo.z = m1.x;
               minfo.w = (m0.w & 0xffffu) | ((m0.z & 0xffffu) << 16);
             }
@@ -808,6 +871,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         c_cur = 0;
         rr = pos - g0;
         qq = 0;
+        rem_l = 0;
         have = true;
       }
       // CIGAR walk (pileup.go:275-363): every M op is one segment; the wave admits up to two
@@ -818,13 +882,37 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         SegIn A = {0, 0, 0}, B = {0, 0, 0};
         uint32_t cB = 0;              // cursor after the last segment taken
         int32_t rrB = 0, qqB = 0;
+        uint4 miA = minfo, miB = minfo;
+        uint32_t mq0A = 0, mq0B = 0;
+        int32_t rsB = 0, rlB = 0, rqB = 0;
+        bool pieces = false;
+        if constexpr (STITCH) pieces = (minfo.y & 0x50000u) == 0x40000u;  // mate with several CIGAR ops
         if (more) {
-          if (aux & AUX_SIMPLE) {
+          const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
+          if (pieces) {
+            const uint32_t* mcg = (const uint32_t*)(P.blob + (uint64_t)minfo.z * 8);
+            const uint32_t mn = minfo.w >> 16;
+            uint32_t c = c_cur;
+            int32_t r_ = rr, q_ = qq, rs = rem_s, rl = rem_l, rq = rem_q;
+            int32_t sA = 0, lA = 0, qA = 0, sB = 0, lB = 0, qB = 0;
+            int32_t msA = 0, mlA = 0, mqA = 0, msB = 0, mlB = 0, mqB = 0;
+            wantA = next_piece(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, rs, rl, rq, mcg, mn, (int32_t)minfo.x,
+                               sA, lA, qA, msA, mlA, mqA);
+            if (wantA)
+              wantB = next_piece(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, rs, rl, rq, mcg, mn, (int32_t)minfo.x,
+                                 sB, lB, qB, msB, mlB, mqB);
+            A.sref = sA; A.len = lA; A.q0 = qA;
+            B.sref = sB; B.len = lB; B.q0 = qB;
+            miA.x = (uint32_t)msA; miA.y = (minfo.y & 0xffff0000u) | (uint32_t)mlA; mq0A = (uint32_t)mqA;
+            miB.x = (uint32_t)msB; miB.y = (minfo.y & 0xffff0000u) | (uint32_t)mlB; mq0B = (uint32_t)mqB;
+            cB = c; rrB = r_; qqB = q_;
+            rsB = rs; rlB = rl; rqB = rq;
+            if (!wantA) more = false;
+          } else if (aux & AUX_SIMPLE) {
             wantA = true;
             A.sref = rr;
             A.len = (int32_t)span;
           } else {
-            const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
             uint32_t c = c_cur;
             int32_t r_ = rr, q_ = qq;
             int32_t sA = 0, lA = 0, qA = 0, sB = 0, lB = 0, qB = 0;
@@ -837,11 +925,15 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         }
         if (!__any(wantA)) break;
-        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec, par, minfo);
+        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec, par, miA, mq0A, miB, mq0B);
         if (wantA) {
           if (!ok) {
             failed = true;
             more = false;
+          } else if (pieces) {
+            c_cur = cB; rr = rrB; qq = qqB;
+            rem_s = rsB; rem_l = rlB; rem_q = rqB;
+            more = rem_l != 0 || c_cur < n_cigar;
           } else if (aux & AUX_SIMPLE) {
             more = false;
           } else {

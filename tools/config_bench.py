@@ -68,6 +68,17 @@ def main():
         opts = O.make_opts(stitch=1, min_base_qual=20, mapq=60)
         ok &= run("c4 deep panel, stitched", regions, bed, [p + 10_000], opts, 2000,
                   insert_mean=170.0, insert_sd=20.0, insert_min=100, insert_max=300)
+    if "c4p" in which:
+        rng = random.Random(4)
+        targets, p = [], 10_000
+        for _ in range(500):
+            targets.append([p, p + 200])
+            p += 200 + rng.randint(300, 3000)
+        bed = {0: targets}
+        regions = [(0, s, e, 10000.0) for s, e in targets]
+        for nm, o in (("minq0", O.make_opts(mapq=60)), ("minq20", O.make_opts(min_base_qual=20, mapq=60))):
+            ok &= run("c4 deep panel, not stitched, " + nm, regions, bed, [p + 10_000], o, 2000,
+                      insert_mean=170.0, insert_sd=20.0, insert_min=100, insert_max=300)
     L = 20_000_000
     if "c1q" in which:
         ok &= run("30x 20 Mb, min-base-qual 20 clip 5", [(0, 0, L - 1000, 30.0)], {0: [[0, L]]}, [L],

@@ -136,6 +136,21 @@ def test_c4_shape_deep_panel(mode):
     assert want[2][:, 0].max() > 1000
 
 
+@pytest.mark.parametrize("clip", [0, 4])
+def test_stitched_mates_with_indels(clip):
+    """Every pair overlaps and most mates carry an indel or a soft clip: the segments of a
+    record are cut at the mate's M ops (pileup.go:366-465 merges the two aligned-base lists)."""
+    opts = O.make_opts(stitch=1, min_base_qual=25, clip=clip)
+    ref_len = [400_000]
+    bed = {0: [[50_000, 120_000], [120_500, 121_000], [130_000, 300_000]]}
+    got, want, sb = _synth_case([(0, 40_000, 320_000, 40.0)], bed, ref_len, opts, with_names=True,
+                                insert_mean=190.0, insert_sd=40.0, insert_min=60, insert_max=400,
+                                frac_softclip=0.25, frac_del=0.25, frac_ins=0.25, frac_hardclip=0.05,
+                                sub_rate=0.05, frac_low_mapq=0.0)
+    assert_same(got, want, "indel mates")
+    assert want[2][:, 9:11].sum() > 10_000  # disagreeing overlaps (counted as X) occur
+
+
 def test_snp_panel_many_tiny_intervals():
     """1-bp targets like cmd/bio-pileup/testdata/common_chr2_subset.bed."""
     rng = random.Random(11)

@@ -155,6 +155,26 @@ def main():
                          f"{cpu_B} aligned bases) in {cpu_s:.1f} s, records in memory -> rows, "
                          f"C restatement of the reference algorithm (oracle/pileup_oracle.c), 1 thread"}
         del wr, wp, wv, dr, dp, dv
+        # the same restatement on all host cores of the box's share: independent position
+        # ranges with a read halo, like the reference's jobs (pileup.go:862-932)
+        from concurrent.futures import ThreadPoolExecutor
+        T = min(16, os.cpu_count() or 1)
+        edges = [L * i // T for i in range(T + 1)]
+
+        def one(i):
+            s, e = edges[i], edges[i + 1]
+            a = int(np.searchsorted(rb.pos, max(0, s - 1024), "left"))
+            b = int(np.searchsorted(rb.pos, e, "left"))
+            _, _, v = O.pileup(oopts, [L], {0: [[s, e]]}, rb.slice(a, b), parallelism=1)
+            return int(v[:, 0].sum())
+        tc = time.perf_counter()
+        with ThreadPoolExecutor(T) as ex:
+            mt_B = sum(ex.map(one, range(T)))
+        mt_s = time.perf_counter() - tc
+        if mt_B != B:
+            raise SystemExit(f"multi-threaded CPU run counted {mt_B} bases, expected {B}")
+        cpu["all_cores"] = {"value": round(mt_B / mt_s / 1e9, 4), "unit": "Gbase/s", "cores": T,
+                            "sample": f"the whole workload as {T} position ranges, one thread each, in {mt_s:.1f} s"}
 
     # HBM traffic is not measurable inside this process (PMC counters need their own
     # rocprofv3 passes): report the committed measurement of the same workload, if any

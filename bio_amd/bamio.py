@@ -24,16 +24,27 @@ class BgzfWriter:
         self.f = open(path, "wb")
         self.buf = bytearray()
         self.level = level
+        self.fpos = 0
+
+    def tell(self):
+        """BGZF virtual offset of the next byte written."""
+        return (self.fpos << 16) | len(self.buf)
+
+    def _emit(self, data):
+        blk = _bgzf_block(data, self.level)
+        self.f.write(blk)
+        self.fpos += len(blk)
 
     def write(self, b):
         self.buf += b
         while len(self.buf) >= _BLOCK:
-            self.f.write(_bgzf_block(bytes(self.buf[:_BLOCK]), self.level))
+            self._emit(bytes(self.buf[:_BLOCK]))
             del self.buf[:_BLOCK]
 
     def close(self):
         if self.buf:
-            self.f.write(_bgzf_block(bytes(self.buf), self.level))
+            self._emit(bytes(self.buf))
+            self.buf = bytearray()
         self.f.write(_EOF)
         self.f.close()
 
@@ -46,10 +57,65 @@ def _reg2bin(beg, end):
     return 0
 
 
-def write_bam(path, ref_names, ref_lens, batch, names=None, aux=None, level=1):
+GBAI_MAGIC = bytes([0x47, 0x42, 0x41, 0x49, 0x01, 0xf1, 0x78, 0x5c, 0x7b, 0xcb, 0xc1, 0xba, 0x08, 0x23, 0xb1, 0x19])
+
+
+def write_bai(path, n_ref, recs):
+    """recs: (ref_id, pos, end, voffset_begin, voffset_end) per record, in file order.  SAM
+    specification section 5.2: bins with chunks, then the 16 kb linear index."""
+    bins = [dict() for _ in range(n_ref)]
+    lin = [[] for _ in range(n_ref)]
+    for ref, pos, end, vb, ve in recs:
+        if ref < 0:
+            continue
+        end = max(end, pos + 1)
+        ch = bins[ref].setdefault(_reg2bin(pos, end), [])
+        if ch and ch[-1][1] == vb:
+            ch[-1][1] = ve
+        else:
+            ch.append([vb, ve])
+        lo, hi = pos >> 14, (end - 1) >> 14
+        v = lin[ref]
+        if len(v) <= hi:
+            v.extend([0] * (hi + 1 - len(v)))
+        for w in range(lo, hi + 1):
+            if v[w] == 0 or vb < v[w]:
+                v[w] = vb
+    out = bytearray(b"BAI\x01" + struct.pack("<i", n_ref))
+    for r in range(n_ref):
+        out += struct.pack("<i", len(bins[r]))
+        for b in sorted(bins[r]):
+            out += struct.pack("<Ii", b, len(bins[r][b]))
+            for vb, ve in bins[r][b]:
+                out += struct.pack("<QQ", vb, ve)
+        out += struct.pack("<i", len(lin[r]))
+        for x in lin[r]:
+            out += struct.pack("<Q", x)
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+def write_gbai(path, recs, every=64):
+    """.gbai (encoding/bam/gindex.go:45-73): gzip of the magic and (ref, pos, seq, voffset)
+    entries: the first record of every reference, then every `every`-th record."""
+    out = bytearray(GBAI_MAGIC)
+    last_ref, last_key, seq = None, None, 0
+    for i, (ref, pos, end, vb, ve) in enumerate(recs):
+        seq = seq + 1 if (ref, pos) == last_key else 0
+        last_key = (ref, pos)
+        if ref != last_ref or i % every == 0:
+            out += struct.pack("<iiIQ", ref, pos, seq, vb)
+        last_ref = ref
+    with gzip.open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+def write_bam(path, ref_names, ref_lens, batch, names=None, aux=None, level=1, index=None):
     """batch: bio_amd.records.RecordBatch (coordinate-sorted).  names: list of bytes/str per
-    record (default: batch names, else r<i>).  aux: optional list of raw aux byte strings."""
+    record (default: batch names, else r<i>).  aux: optional list of raw aux byte strings.
+    index: "bai" / "gbai" also writes <path>.bai / <path>.gbai."""
     w = BgzfWriter(path, level)
+    irecs = []
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(
         f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(ref_names, ref_lens))
     hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(ref_names))
@@ -79,8 +145,15 @@ def write_bam(path, ref_names, ref_lens, batch, names=None, aux=None, level=1):
         body += bytes(b.qual[int(b.qual_off[i]):int(b.qual_off[i]) + ls])
         if aux is not None:
             body += aux[i]
+        vb = w.tell()
         w.write(struct.pack("<i", len(body)) + body)
+        if index:
+            irecs.append((int(b.ref_id[i]), pos, pos + max(span, 1), vb, w.tell()))
     w.close()
+    if index == "bai":
+        write_bai(path + ".bai", len(ref_names), irecs)
+    elif index == "gbai":
+        write_gbai(path + ".gbai", irecs)
 
 
 def write_fasta(path, names, seqs, width=60, gz=False):

@@ -1,6 +1,7 @@
 // bam.cpp -- sequential BGZF/BAM reader feeding bp_record_batch (reference: encoding/bam
 // unmarshal.go:126-224 for the record layout, encoding/bamprovider/provider.go:141-166 for the
 // iterator contract).  BGZF blocks are inflated a batch at a time on a few host threads.
+#include <stdio.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -56,6 +57,9 @@ struct BamReader::Impl {
   std::vector<uint8_t> raw;  // compressed batch
   struct Blk { size_t off, clen, isize, out; };
   std::vector<Blk> blks;
+  uint64_t file_pos = 0;  // file offset of the next byte fread returns
+  // (offset in buf, file offset) of the blocks buf holds bytes of, ascending
+  std::vector<std::pair<size_t, uint64_t>> marks;
 
   ~Impl() { if (f) fclose(f); }
 
@@ -63,6 +67,11 @@ struct BamReader::Impl {
   std::string Refill() {
     if (rd > 0) {
       buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)rd);
+      // keep the mark of the block the tail starts in (its offset becomes 0) and later ones
+      size_t k = 0;
+      while (k + 1 < marks.size() && marks[k + 1].first <= rd) k++;
+      marks.erase(marks.begin(), marks.begin() + (ptrdiff_t)k);
+      for (auto& mk : marks) mk.first = mk.first > rd ? mk.first - rd : 0;
       rd = 0;
     }
     raw.clear();
@@ -70,6 +79,7 @@ struct BamReader::Impl {
     size_t out_total = buf.size();
     while (!file_eof && (int)blks.size() < kBatchBlocks) {
       uint8_t hd[18];
+      const uint64_t block_at = file_pos;
       size_t got = fread(hd, 1, 18, f);
       if (got == 0) { file_eof = true; break; }
       if (got != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4))
@@ -96,6 +106,8 @@ struct BamReader::Impl {
       size_t isize = U32(raw.data() + off + (size_t)remaining - 4);
       if (isize > 65536) return "bgzf: invalid uncompressed size";
       blks.push_back({off, (size_t)remaining - 8, isize, out_total});
+      if (isize) marks.emplace_back(out_total, block_at);
+      file_pos = block_at + (uint64_t)total;
       out_total += isize;
     }
     buf.resize(out_total);
@@ -170,6 +182,32 @@ std::string BamReader::Open(const std::string& path) {
     m.rd += 8 + (size_t)l_name;
   }
   return "";
+}
+
+std::string BamReader::Seek(uint64_t voffset) {
+  Impl& m = *impl_;
+  const uint64_t coff = voffset >> 16;
+  if (fseeko(m.f, (off_t)coff, SEEK_SET) != 0) return "bgzf: seek failed";
+  m.file_pos = coff;
+  m.file_eof = false;
+  m.buf.clear();
+  m.rd = 0;
+  m.marks.clear();
+  std::string err = m.Refill();
+  if (!err.empty()) return err;
+  if ((voffset & 0xffff) > m.buf.size()) return "bgzf: virtual offset past the end of its block";
+  m.rd = (size_t)(voffset & 0xffff);
+  return "";
+}
+
+uint64_t BamReader::BlockOffset() const {
+  const Impl& m = *impl_;
+  uint64_t at = m.file_pos;
+  for (const auto& mk : m.marks) {
+    if (mk.first > m.rd) break;
+    at = mk.second;
+  }
+  return at;
 }
 
 int BamReader::Next(Raw* r) {

@@ -90,12 +90,35 @@ class BamReader {
   };
   int Next(Raw* r);
   const std::string& err() const { return err_; }
+  // Continues reading at a BGZF virtual offset (compressed block offset << 16 | offset inside
+  // the inflated block), e.g. one taken from an index.
+  std::string Seek(uint64_t voffset);
+  // File offset of the BGZF block the next record starts in.
+  uint64_t BlockOffset() const;
 
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
   BamHeader header_;
   std::string err_;
+};
+
+// .bai (SAM spec section 5.2; only the linear index is used) or .gbai
+// (encoding/bam/gindex.go:35-73) index of a coordinate-sorted BAM.
+class BamIndex {
+ public:
+  std::string Load(const std::string& path);
+  bool loaded() const { return loaded_; }
+  // A virtual offset from which reading forward meets every record at or after (ref, pos)
+  // (conservative, like bamIterator.reset, bamprovider.go:286-348); false when the index shows
+  // that no mapped record lies at or after it.
+  bool Offset(int32_t ref, int32_t pos, uint64_t* voffset) const;
+
+ private:
+  struct GEntry { int32_t ref, pos; uint32_t seq; uint64_t voff; };
+  bool loaded_ = false, gbai_ = false;
+  std::vector<std::vector<uint64_t>> lin_;  // .bai: per reference, ioffset of each 16 kb window
+  std::vector<GEntry> g_;                   // .gbai entries, ascending (mapped first)
 };
 
 // Integer value of a 2-character aux tag (A/c/C/s/S/i/I types); returns false if absent.

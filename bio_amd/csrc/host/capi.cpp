@@ -153,4 +153,40 @@ int bio_bam_scan(const char* path, int64_t* n_records, int64_t* sum_l_seq, int64
   return Ok(err, errlen);
 }
 
+int bio_bam_seek_scan(const char* bam_path, const char* index_path, int32_t ref_id, int32_t pos, int32_t* found,
+                      int32_t* first_ref, int32_t* first_pos, int64_t* n_skipped, int64_t* n_at_or_after, char* err,
+                      size_t errlen) {
+  bio::BamReader rd;
+  std::string m = rd.Open(Str(bam_path));
+  if (!m.empty()) return Fail(m, err, errlen);
+  bio::BamIndex ix;
+  m = ix.Load(Str(index_path));
+  if (!m.empty()) return Fail(m, err, errlen);
+  uint64_t voff = 0;
+  const bool ok = ix.Offset(ref_id, pos, &voff);
+  if (found) *found = ok ? 1 : 0;
+  int64_t skipped = 0, after = 0;
+  int32_t fr = -1, fp = -1;
+  if (ok) {
+    if ((voff >> 16) > rd.BlockOffset()) {
+      m = rd.Seek(voff);
+      if (!m.empty()) return Fail(m, err, errlen);
+    }
+    bio::BamReader::Raw r;
+    int rc;
+    bool first = true;
+    while ((rc = rd.Next(&r)) == 1) {
+      if (first) { fr = r.ref_id; fp = r.pos; first = false; }
+      const bool before = r.ref_id >= 0 && (r.ref_id < ref_id || (r.ref_id == ref_id && r.pos < pos));
+      if (before) skipped++; else after++;
+    }
+    if (rc < 0) return Fail(rd.err(), err, errlen);
+  }
+  if (first_ref) *first_ref = fr;
+  if (first_pos) *first_pos = fp;
+  if (n_skipped) *n_skipped = skipped;
+  if (n_at_or_after) *n_at_or_after = after;
+  return Ok(err, errlen);
+}
+
 }  // extern "C"

@@ -57,7 +57,7 @@ int BioPileupMain(int argc, char** argv) {
       {"region", Flag::kString, &o.Region,
        "Restrict pileup computation to the specified region. Format as <contig ID>:<1-based first pos>-<last "
        "pos>, <contig ID>:<1-based pos>, or just <contig ID>; this xor -bed required"},
-      {"index", Flag::kString, &o.BamIndexPath, "Input BAM index path (accepted; the BAM is read sequentially)"},
+      {"index", Flag::kString, &o.BamIndexPath, "Input BAM index path (.bai or .gbai; default <bam>.bai, then <bam>.gbai, if present)"},
       {"clip", Flag::kInt, &o.Clip, "Number of bases on end of each read to treat as minimum-quality"},
       {"cols", Flag::kString, &o.Cols,
        "Output TSV column sets. #CHROM/POS/REF(/ALT) are always present. Currently supported optional sets are "

@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -27,6 +28,41 @@ namespace {
 
 constexpr int64_t kSubmitRecords = 1 << 20;  // records per bp_submit
 constexpr int64_t kRowChunk = 1 << 20;       // rows per bp_rows copy
+// With an index, stretches of the BAM that start more than this many positions before the
+// next padded BED interval are skipped (the reference's position shards are this long, and
+// it never opens a shard that misses the BED: pileup.go:1073-1084, pileup_support.go:71-85).
+constexpr int64_t kSeekGap = 100000;
+
+// Walks the padded BED intervals [start - pad, end + pad_end) in step with the sorted records.
+class NeedCursor {
+ public:
+  NeedCursor(const BEDUnion& bed, int64_t pad, int64_t pad_end) : bed_(bed), pad_(pad), pad_end_(pad_end) {}
+  // The first padded interval that ends after (ref, pos): false when there is none; else
+  // (*nref, *nstart) is its start, which may lie at or before pos.
+  bool Next(int ref, int64_t pos, int* nref, int64_t* nstart) {
+    if (ref != ref_) { ref_ = ref; k_ = 0; }
+    for (size_t r = (size_t)ref; r < bed_.id_map.size(); r++) {
+      const std::vector<PosType>& e = bed_.id_map[r];
+      size_t k = 0;
+      if ((int)r == ref_) {
+        while (k_ + 1 < e.size() && (int64_t)e[k_ + 1] + pad_end_ <= pos) k_ += 2;
+        k = k_;
+      }
+      if (k + 1 < e.size()) {
+        *nref = (int)r;
+        *nstart = std::max<int64_t>(0, (int64_t)e[k] - pad_);
+        return true;
+      }
+    }
+    return false;
+  }
+
+ private:
+  const BEDUnion& bed_;
+  int64_t pad_, pad_end_;
+  int ref_ = -1;
+  size_t k_ = 0;
+};
 
 int64_t JobSpan() {
   // Positions per job.  BIO_PILEUP_JOB_SPAN exists for tests of the halo logic.
@@ -36,6 +72,15 @@ int64_t JobSpan() {
     if (v > 0) return v;
   }
   return 1ll << 28;
+}
+
+// BIO_PILEUP_STATS=1 prints one line of counters and stage times to stderr at the end.
+struct Stats {
+  int64_t records_read = 0, records_kept = 0, seeks = 0, jobs = 0;
+  double submit_s = 0, close_s = 0, total_s = 0;
+};
+double Now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 struct Job {
@@ -206,6 +251,20 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (!err.empty()) return err;
   }
   const BamHeader& hd = bam.header();
+  // The index is optional here (the reference requires one, bamprovider.go:76-100): -index,
+  // else <bam>.bai, else <bam>.gbai if present; without one the BAM is read front to back.
+  BamIndex index;
+  {
+    std::string ipath = opts.BamIndexPath;
+    if (ipath.empty()) {
+      if (access((xampath + ".bai").c_str(), R_OK) == 0) ipath = xampath + ".bai";
+      else if (access((xampath + ".gbai").c_str(), R_OK) == 0) ipath = xampath + ".gbai";
+    }
+    if (!ipath.empty()) {
+      std::string err = index.Load(ipath);
+      if (!err.empty()) return err;
+    }
+  }
   BEDUnion bed;
   Entry region;
   if (!opts.Region.empty()) {
@@ -302,6 +361,8 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   const int64_t pad = opts.Stitch ? 2 * (int64_t)opts.MaxReadSpan : (int64_t)opts.MaxReadSpan;
   const int64_t pad_end = opts.Stitch ? pad : 0;
   drv.SetPadding(opts.Stitch ? pad : 0);
+  Stats st;
+  const double t_start = Now();
   std::deque<RecordBatchBuilder> pend(1);
   pend[0].keep_names = true;  // stitching keys on names; error messages quote them
   size_t ji = 0;
@@ -313,8 +374,13 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     return e;
   };
   auto close_job = [&]() -> std::string {
+    double t0 = Now();
     std::string e = drv.Submit(&pend[0]);
+    st.submit_s += Now() - t0;
+    t0 = Now();
     if (e.empty()) e = drv.CloseJob(jobs[ji]);
+    st.close_s += Now() - t0;
+    st.jobs++;
     open = false;
     ji++;
     pend.pop_front();
@@ -326,10 +392,25 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   };
   BamReader::Raw r;
   int32_t last_ref = -1, last_pos = -1;
-  while (ji < jobs.size()) {
+  NeedCursor need(bed, pad, pad_end);
+  int skip_ref = -1;  // after a seek: records before (skip_ref, skip_pos) are not wanted
+  int64_t skip_pos = 0;
+  bool no_records = false;
+  if (index.loaded() && region_ref >= 0) {
+    // bamIterator.reset (bamprovider.go:286-348): start at the region's first position
+    uint64_t voff = 0;
+    if (!index.Offset(region_ref, region.start0, &voff)) {
+      no_records = true;  // no record at or after the region start
+    } else if ((voff >> 16) > bam.BlockOffset()) {
+      err = bam.Seek(voff);
+      st.seeks++;
+    }
+  }
+  while (err.empty() && !no_records && ji < jobs.size()) {
     int rc = bam.Next(&r);
     if (rc < 0) { err = bam.err(); break; }
     if (rc == 0) break;
+    st.records_read++;
     if (r.ref_id < 0) break;  // unplaced reads sort last
     if (r.ref_id < last_ref || (r.ref_id == last_ref && r.pos < last_pos)) {
       err = "Pileup: BAM is not coordinate-sorted at " + std::string(r.name, r.l_name);
@@ -340,6 +421,22 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (region_ref >= 0) {  // iterator of the single region shard (bamprovider.go:417-435)
       if (r.ref_id < region_ref || (r.ref_id == region_ref && r.pos < region.start0)) continue;
       if (r.ref_id > region_ref || r.pos >= region.end) break;
+    } else if (index.loaded()) {
+      if (r.ref_id < skip_ref || (r.ref_id == skip_ref && r.pos < skip_pos)) continue;
+      int nref = 0;
+      int64_t nstart = 0;
+      if (!need.Next(r.ref_id, r.pos, &nref, &nstart)) break;  // past the last BED interval
+      if (nref != r.ref_id || nstart - r.pos > kSeekGap) {
+        uint64_t voff = 0;
+        if (!index.Offset(nref, (int32_t)nstart, &voff)) break;  // no records from there on
+        skip_ref = nref;
+        skip_pos = nstart;
+        if ((voff >> 16) > bam.BlockOffset()) {
+          if (!(err = bam.Seek(voff)).empty()) break;
+          st.seeks++;
+        }
+        continue;
+      }
     }
     // jobs whose padded range ends at or before this record are complete
     while (ji < jobs.size() &&
@@ -368,6 +465,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     // scans them.
     if (!open && !(err = open_job()).empty()) break;
     AppendRecord(&pend[0], r);
+    st.records_kept++;
     for (size_t k = ji + 1; k < jobs.size() && jobs[k].ref == r.ref_id && (int64_t)jobs[k].start - pad <= r.pos; k++) {
       if (pend.size() <= k - ji) {
         pend.emplace_back();
@@ -375,7 +473,12 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
       }
       AppendRecord(&pend[k - ji], r);
     }
-    if (pend[0].size() >= kSubmitRecords && !(err = drv.Submit(&pend[0])).empty()) break;
+    if (pend[0].size() >= kSubmitRecords) {
+      const double t0 = Now();
+      err = drv.Submit(&pend[0]);
+      st.submit_s += Now() - t0;
+      if (!err.empty()) break;
+    }
   }
   // jobs after the last record still emit their (zero) rows (flushEmptyContigs,
   // pileup_support.go:112-123)
@@ -391,6 +494,13 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     std::string e = s.writer->Close();
     if (!e.empty()) return e;
   }
+  st.total_s = Now() - t_start;
+  if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
+    fprintf(stderr,
+            "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
+            "submit_s=%.3f close_s=%.3f read_s=%.3f total_s=%.3f\n",
+            (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
+            index.loaded() ? 1 : 0, st.submit_s, st.close_s, st.total_s - st.submit_s - st.close_s, st.total_s);
   return "";
 }
 

@@ -117,3 +117,14 @@ def bam_scan(path):
     if lib.bio_bam_scan(path.encode(), C.byref(a), C.byref(b), C.byref(c), C.byref(d), e, len(e)):
         raise ValueError(e.value.decode())
     return a.value, b.value, c.value, d.value
+
+
+def bam_seek_scan(bam, index, ref_id, pos):
+    """-> (found, first_ref, first_pos, n_skipped, n_at_or_after): the driver's index lookup and
+    seek, then a read to the end of the file"""
+    lib = _abi.load()
+    f, fr, fp, sk, af, e = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), _err()
+    if lib.bio_bam_seek_scan(bam.encode(), index.encode(), ref_id, pos, C.byref(f), C.byref(fr), C.byref(fp),
+                             C.byref(sk), C.byref(af), e, len(e)):
+        raise ValueError(e.value.decode())
+    return bool(f.value), fr.value, fp.value, sk.value, af.value

@@ -77,6 +77,16 @@ int64_t bio_fasta_seq8(const char* path, const char* name, uint8_t* seq8, int64_
 int bio_bam_scan(const char* path, int64_t* n_records, int64_t* sum_l_seq, int64_t* sum_n_cigar,
                  int32_t* n_ref, char* err, size_t errlen);
 
+/* Index lookup + seek as the driver does them (bamIterator.reset, bamprovider.go:286-348;
+ * .gbai: encoding/bam/gindex.go:35-121; .bai: SAM specification 5.2): loads index_path
+ * (.bai or .gbai by suffix), asks for (ref_id, pos), seeks there and reads to the end of the
+ * file.  *found = 0 when the index shows no record at or after the target.  *first_ref/pos =
+ * the first record met, *n_skipped = records met that lie before the target,
+ * *n_at_or_after = the rest (unmapped included); for tests of the index readers. */
+int bio_bam_seek_scan(const char* bam_path, const char* index_path, int32_t ref_id, int32_t pos,
+                      int32_t* found, int32_t* first_ref, int32_t* first_pos, int64_t* n_skipped,
+                      int64_t* n_at_or_after, char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -310,6 +310,65 @@ def test_region_mode(tmp_path):
     assert c.read("r.basestrand.tsv").split("\n")[1].split("\t")[:2] == ["chr2", "77"]
 
 
+def test_index_seeks_change_nothing(tmp_path):
+    """With a .bai or .gbai the driver skips the stretches of the BAM that no BED interval
+    needs (bamIterator.reset, bamprovider.go:286-348); the files are those of a front-to-back
+    read, and far fewer records are decoded."""
+    import re
+    import shutil
+    rng = random.Random(23)
+    ref_lens, ref_names = [700_000, 50_000, 400_000], ["chr1", "chr2", "chr3"]
+    recs = []
+    for r in (0, 2):
+        part = random_records(rng, 9000, ref_len=ref_lens[r], read_len=100)
+        for x in part:
+            x["name"] = f"c{r}{x['name']}"
+            x["mate_ref_id"] = r
+            x["ref_id"] = r
+        recs += part
+    recs.sort(key=lambda x: (x["ref_id"], x["pos"]))
+    batch = R.from_records(recs)
+    ascii_ = ["".join(rng.choice("ACGT") for _ in range(l)) for l in ref_lens]
+    bed = {0: [[1000, 1500], [300_000, 300_400], [650_000, 650_100]], 1: [[10, 20]], 2: [[200_000, 200_300]]}
+    fa, bedp = str(tmp_path / "r.fa"), str(tmp_path / "t.bed")
+    bamio.write_fasta(fa, ref_names, ascii_)
+    bamio.write_bed(bedp, [(r, s, e) for r in sorted(bed) for s, e in bed[r]], ref_names)
+    plain = str(tmp_path / "plain.bam")
+    bamio.write_bam(plain, ref_names, ref_lens, batch)
+    exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
+    env = dict(os.environ, BIO_PILEUP_STATS="1")
+
+    def run(bam, tag, *extra):
+        r = subprocess.run([exe, *extra, "-format", "basestrand-tsv", "-mapq", "0", "-out", str(tmp_path / tag), bam, fa],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"records_read=(\d+) records_kept=(\d+) seeks=(\d+)", r.stderr)
+        return open(str(tmp_path / tag) + ".basestrand.tsv").read(), [int(x) for x in m.groups()]
+
+    want = render_basestrand(O.pileup(O.make_opts(mapq=0), ref_lens, bed, batch), ref_names, ascii_)
+    got, (n_read, _, seeks) = run(plain, "p", "-bed", bedp)
+    assert got == want and seeks == 0 and n_read == batch.n
+    shard, n = O.region_shard(2, 199_000, 201_000)
+    want_region = render_basestrand(O.pileup(O.make_opts(mapq=0), ref_lens, {2: [[199_000, 201_000]]}, batch,
+                                             shards=shard, n_shards=n), ref_names, ascii_)
+    for kind in ("bai", "gbai"):
+        bam = str(tmp_path / f"{kind}.bam")
+        bamio.write_bam(bam, ref_names, ref_lens, batch, index=kind)
+        got, (n_read, _, seeks) = run(bam, kind, "-bed", bedp)
+        assert got == want, kind
+        assert seeks >= 4 and n_read < batch.n // 4, (kind, seeks, n_read)
+        got, (n_read, _, seeks) = run(bam, kind + "r", "-region", "chr3:199001-201000")
+        assert got == want_region and seeks == 1 and n_read < batch.n // 8, (kind, seeks, n_read)
+        # -index names the file explicitly
+        moved = str(tmp_path / f"elsewhere.{kind}")
+        shutil.move(bam + "." + kind, moved)
+        got, (n_read, _, seeks) = run(bam, kind + "x", "-bed", bedp, "-index", moved)
+        assert got == want and seeks >= 4
+    r = subprocess.run([exe, "-bed", bedp, "-index", str(tmp_path / "nope.bai"), "-out", str(tmp_path / "z"), plain, fa],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no such file" in r.stderr
+
+
 def test_bag_filters(tmp_path):
     """-min-bag-depth / -remove-sq read DS / DL aux tags on the host (pileup.go:695-716).
     The hts accessors are not in the reference tree: absent-tag behaviour is parity unpinned."""

@@ -192,6 +192,56 @@ def test_bam_reader_rejects_corruption(tmp_path):
         host.bam_scan(str(tmp_path / "missing.bam"))
 
 
+def _indexed_bam(tmp_path, kind):
+    """3 contigs, the middle one without reads; a gap on the last one"""
+    rng = random.Random(11)
+    recs = random_records(rng, 2500, ref_len=200_000, read_len=100, n_ref=1)
+    more = [dict(r, ref_id=2, mate_ref_id=2) for r in random_records(rng, 2500, ref_len=90_000, read_len=100)]
+    far = [dict(r, ref_id=2, mate_ref_id=2, pos=r["pos"] + 400_000, mate_pos=r["mate_pos"] + 400_000)
+           for r in random_records(rng, 800, ref_len=50_000, read_len=100)]
+    batch = from_records(sorted(recs + more + far, key=lambda r: (r["ref_id"], r["pos"])))
+    path = str(tmp_path / f"i_{kind}.bam")
+    bamio.write_bam(path, ["c0", "c1", "c2"], [200_000, 50_000, 500_000], batch, index=kind)
+    return path, path + "." + kind, batch
+
+
+@pytest.mark.parametrize("kind", ["bai", "gbai"])
+def test_bam_index_seek_reaches_every_wanted_record(tmp_path, kind):
+    """bamIterator.reset + Scan (bamprovider.go:286-348, 417-435): the offset an index gives
+    is at or before the first record at or after the target, and close to it."""
+    path, ipath, b = _indexed_bam(tmp_path, kind)
+    total = b.n
+    key = b.ref_id.astype(np.int64) * (1 << 32) + b.pos
+    for ref, pos in [(0, 0), (0, 1), (0, 99_999), (0, 150_000), (0, 199_999), (1, 0), (1, 40_000), (2, 0),
+                     (2, 45_000), (2, 95_000), (2, 250_000), (2, 400_000), (2, 430_000)]:
+        want = int(total - np.searchsorted(key, ref * (1 << 32) + pos, "left"))
+        found, fr, fp, skipped, after = host.bam_seek_scan(path, ipath, ref, pos)
+        assert found and after == want, (kind, ref, pos, after, want)
+        # the seek saves work: far fewer records are skipped than lie before the target
+        assert skipped <= min(total - want, 700), (kind, ref, pos, skipped)
+    # past every record: the .bai shows there is nothing; a .gbai lands on its last entry
+    found, fr, fp, skipped, after = host.bam_seek_scan(path, ipath, 2, 499_000)
+    assert after == 0 and (not found or skipped < 700)
+
+
+def test_bam_index_errors(tmp_path):
+    path, ipath, _ = _indexed_bam(tmp_path, "bai")
+    with pytest.raises(ValueError, match="no such file"):
+        host.bam_seek_scan(path, str(tmp_path / "nope.bai"), 0, 0)
+    bad = str(tmp_path / "bad.bai")
+    open(bad, "wb").write(b"BAM\x01" + open(ipath, "rb").read()[4:])
+    with pytest.raises(ValueError, match="bad magic"):
+        host.bam_seek_scan(path, bad, 0, 0)
+    open(bad, "wb").write(open(ipath, "rb").read()[:-5])
+    with pytest.raises(ValueError, match="truncated"):
+        host.bam_seek_scan(path, bad, 0, 0)
+    badg = str(tmp_path / "bad.gbai")
+    with gzip.open(badg, "wb") as f:
+        f.write(b"GBAI" + bytes(12) + bytes(20))
+    with pytest.raises(ValueError, match="bad magic"):
+        host.bam_seek_scan(path, badg, 0, 0)
+
+
 # ------------------------------------------------------------------ snp.Pileup validation
 def _inputs(tmp_path, ref_len=20000, fa_len=None):
     path, _ = _small_bam(tmp_path, n=50, ref_len=ref_len)

@@ -568,20 +568,38 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
   const int nthreads = pack_threads();
   std::vector<int32_t> spans;
   std::vector<uint8_t> simple;
-  std::vector<uint64_t> boff;
+  std::vector<uint64_t> boff, qoff;
+  // a record longer than the core can say (0xffff) passes no max-read-len: no payload kept
+  auto plen = [](uint32_t l) { return l > 0xffffu ? 0u : l; };
   int64_t i0 = 0;
   while (i0 < b->n) {
     // slice bounded by staging capacity
     int64_t i1 = i0;
     uint64_t bytes = 0;
     boff.clear();
+    qoff.clear();
     while (i1 < b->n && (size_t)(i1 - i0) < kStageReads) {
-      uint64_t bb = blob_bytes(b->n_cigar[i1], b->l_seq[i1]);
-      if (bb > kStageBlob) return fail(h, BP_EINVAL, "bp_submit: record payload of %llu bytes", (unsigned long long)bb);
-      if (bytes + bb > kStageBlob) break;
-      boff.push_back(bytes);
-      bytes += bb;
-      i1++;
+      // one group: base parts back to back, then the qual parts
+      int64_t g1 = i1;
+      uint64_t ga = 0, gq = 0;
+      while (g1 < b->n && g1 - i1 < kGroupRecs && (size_t)(g1 - i0) < kStageReads) {
+        const uint64_t a = base_part_bytes(b->n_cigar[g1], plen(b->l_seq[g1])), q = qual_part_bytes(plen(b->l_seq[g1]));
+        if (a + q > kGroupBytes) return fail(h, BP_EINVAL, "bp_submit: record payload of %llu bytes", (unsigned long long)(a + q));
+        if (ga + gq + a + q > kGroupBytes) break;
+        ga += a;
+        gq += q;
+        g1++;
+      }
+      if (bytes + ga + gq > kStageBlob) break;
+      uint64_t ao = bytes, qo = bytes + ga;
+      for (int64_t i = i1; i < g1; i++) {
+        boff.push_back(ao);
+        qoff.push_back(qo);
+        ao += base_part_bytes(b->n_cigar[i], plen(b->l_seq[i]));
+        qo += qual_part_bytes(plen(b->l_seq[i]));
+      }
+      bytes += ga + gq;
+      i1 = g1;
     }
     const size_t ns = (size_t)(i1 - i0);
     if ((uint64_t)h->blob_used + bytes / 8 > 0xffffffffull)
@@ -602,7 +620,7 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
       for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
         const int64_t i = i0 + (int64_t)k;
         ReadCore& rc = st->cores[k];
-        const uint32_t n_cigar = b->n_cigar[i], l = b->l_seq[i];
+        const uint32_t n_cigar = b->n_cigar[i], l = plen(b->l_seq[i]);
         rc.pos = b->pos[i];
         rc.flags = b->flags[i];
         rc.mapq = b->mapq[i];
@@ -610,8 +628,8 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
                            (b->ref_id[i] == b->mate_ref_id[i] ? AUX_MATE_SAME : 0));
         rc.n_cigar = (uint16_t)n_cigar;
         rc.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
-        rc.l_seq = (uint16_t)std::min<uint32_t>(l, 0xffffu);
-        rc.pad = 0;
+        rc.l_seq = (uint16_t)std::min<uint32_t>(b->l_seq[i], 0xffffu);
+        rc.qdelta = (uint16_t)((qoff[k] - boff[k]) / 8);
         rc.blob = blob_base + (uint32_t)(boff[k] / 8);
         for (uint32_t c = 0; c < 3; c++) rc.cig[c] = c < n_cigar ? b->cigar[b->cigar_off[i] + c] : 0u;
         uint8_t* d = st->blob + boff[k];
@@ -620,9 +638,9 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
         if (ncp != n_cigar) memset(d + (size_t)n_cigar * 4, 0, 4);
         d += (size_t)ncp * 4;
         const uint32_t U = blob_units(l);
-        memcpy(d, b->qual + b->qual_off[i], l);
-        memset(d + l, 0, (size_t)U * 8 - l);
-        d += (size_t)U * 8;
+        uint8_t* dq = st->blob + qoff[k];
+        memcpy(dq, b->qual + b->qual_off[i], l);
+        memset(dq + l, 0, (size_t)U * 8 - l);
         const uint32_t sb = (l + 1) / 2;
         // device layout keeps the first base of a byte in the LOW nibble (BAM: high), so 8
         // bases are one little-endian dword with base k at bits 4k
@@ -630,9 +648,9 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
           const uint8_t* sp = b->seq + b->seq_off[i];
           for (uint32_t x = 0; x < sb; x++) d[x] = (uint8_t)((sp[x] << 4) | (sp[x] >> 4));
         }
-        const uint64_t tail = blob_bytes(n_cigar, l) - (uint64_t)ncp * 4 - (uint64_t)U * 8 - sb;
+        const uint64_t tail = base_part_bytes(n_cigar, l) - (uint64_t)ncp * 4 - sb;
         memset(d + sb, 0, (size_t)tail);
-        local += 32 + 4 * (int64_t)n_cigar + (l + 1) / 2 + l;
+        local += 32 + 4 * (int64_t)n_cigar + ((int64_t)b->l_seq[i] + 1) / 2 + b->l_seq[i];
       }
       algo.fetch_add(local);
     });

@@ -19,8 +19,8 @@ struct ReadCore {
   uint16_t n_cigar;
   uint16_t span;
   uint16_t l_seq;    // clamped to 0xffff (longer records never pass max-read-len)
-  uint16_t pad;
-  uint32_t blob;     // offset of the record's payload in 8-byte units
+  uint16_t qdelta;   // the quals start this many 8-byte units after `blob`
+  uint32_t blob;     // offset of the record's CIGAR + bases in 8-byte units
   uint32_t cig[3];   // first three CIGAR ops (the payload holds all of them)
 };
 static_assert(sizeof(ReadCore) == 32, "ReadCore must be 32 bytes");
@@ -30,17 +30,26 @@ enum : uint8_t {
   AUX_MATE_SAME = 2   // Ref == MateRef (first test of pileup.GetStrand, common.go:95)
 };
 
-// Payload ("blob") of a record, 8-byte aligned:
-//   uint32 cigar[n_cigar rounded up to even]
-//   uint8  qual[8*U]      U = ceil(l_seq/8); pad bytes 0
-//   uint8  seq4[4*U]      packed 4-bit bases (BAM codes), first base of a byte in the LOW
-//                         nibble (BAM has it in the high one); pad nibbles 0
-//   pad to 8 bytes
+// Payload of a record, two 8-byte aligned parts (U = ceil(l_seq/8)):
+//   base part   uint32 cigar[n_cigar rounded up to even]
+//               uint8  seq4[4*U]   packed 4-bit bases (BAM codes), first base of a byte in the
+//                                  LOW nibble (BAM has it in the high one); pad nibbles 0
+//               pad to 8 bytes
+//   qual part   uint8  qual[8*U]   pad bytes 0
+// Records are packed in groups of up to kGroupRecs: the base parts of a group back to back,
+// then its qual parts.  A run that never looks at quals (min_base_qual 0 without stitching:
+// every base passes, pileup.go:227) then never pulls them through HBM: they are whole
+// kilobytes apart from anything it loads, not interleaved with it.
+constexpr int kGroupRecs = 128;
+constexpr uint64_t kGroupBytes = 400 << 10;  // keeps qdelta (16 bits of 8-byte units) in range
 inline uint32_t blob_units(uint32_t l_seq) { return (l_seq + 7) >> 3; }
-inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq) {
-  uint64_t u = blob_units(l_seq);
-  uint64_t b = (uint64_t)((n_cigar + 1) & ~1u) * 4 + 12 * u;
+inline uint64_t base_part_bytes(uint32_t n_cigar, uint32_t l_seq) {
+  uint64_t b = (uint64_t)((n_cigar + 1) & ~1u) * 4 + 4 * (uint64_t)blob_units(l_seq);
   return (b + 7) & ~(uint64_t)7;
+}
+inline uint64_t qual_part_bytes(uint32_t l_seq) { return 8 * (uint64_t)blob_units(l_seq); }
+inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq) {
+  return base_part_bytes(n_cigar, l_seq) + qual_part_bytes(l_seq);
 }
 
 // A genomic window: at most W consecutive positions of one reference, covering BED

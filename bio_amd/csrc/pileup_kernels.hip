@@ -190,9 +190,9 @@ struct SegExtra {
   // segment wherever the mate's next M op starts, so there is at most one): x = its start
   // relative to the window start, y = its length | this record is the one that found its
   // mate << 17 | has a mate << 18, z = mate payload offset, w = mate l_seq | n_cigar << 16;
-  // s_mq0 = read index of its first base
+  // s_mx = read index of its first base | mate qdelta << 16
   uint4 s_mate[kSegCap];
-  uint16_t s_mq0[kSegCap];
+  uint32_t s_mx[kSegCap];
   uint8_t qthr[96];             // KernelParams::qthr, "never" clamped to 96
 };
 struct NoExtra {};
@@ -305,16 +305,17 @@ __device__ __forceinline__ bool seg_extent(const SegIn& g, uint32_t wlen, int32_
 template <bool EXTRA>
 __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, uint32_t us, const SegIn& g,
                                           int32_t s1, int32_t e1, uint32_t jlo, uint32_t U, uint32_t blob,
-                                          uint32_t lseqnc, uint32_t sslot, int32_t rec, uint4 minfo,
-                                          uint32_t mq0) {
-  // byte offsets inside the record payload [cigar padded to even][qual 8*Ur][seq 4*Ur]
-  const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
+                                          uint32_t lseqnc, uint32_t qdelta, uint32_t sslot, int32_t rec,
+                                          uint4 minfo, uint32_t mx) {
+  // byte offsets from the record's base part [cigar padded to even][seq 4*Ur]; its quals
+  // start 8 * qdelta bytes after it
+  const uint32_t nc = lseqnc >> 16;
   const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
   const int32_t d = g.q0 - g.sref;                       // read index of window position 0
   const int32_t b_first = d + (int32_t)(jlo * 32);       // read index of the first unit's base 0
-  const int32_t qo = cigb + b_first;                     // >= -24: the payload buffer starts with a pad
-  const int32_t so = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b_first >> 1);
-  const uint64_t sa = (uint64_t)blob * 8 + (uint64_t)(uint32_t)(so & ~3);
+  const int32_t qo = (int32_t)(qdelta * 8u) + b_first;   // >= -23: the payload buffer starts with a pad
+  const int32_t so = cigb + (b_first >> 1);              // >= -8
+  const uint64_t sa = (uint64_t)((int64_t)((uint64_t)blob * 8) + (int64_t)(so & ~3));  // so may be < 0
   const uint32_t noff = 2u * ((uint32_t)so & 3u) + ((uint32_t)d & 1u);
   uint4 r;
   r.x = (uint32_t)sa;
@@ -329,7 +330,7 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
     S.ex.s_lseqnc[idx] = lseqnc;
     S.ex.s_rec[idx] = rec;
     S.ex.s_mate[idx] = minfo;
-    S.ex.s_mq0[idx] = (uint16_t)mq0;
+    S.ex.s_mx[idx] = mx;
   }
   for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
 }
@@ -342,8 +343,8 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
 template <bool EXTRA>
 __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
                                           const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
-                                          uint32_t sslot, int32_t rec, uint32_t par, uint4 miA, uint32_t mq0A,
-                                          uint4 miB, uint32_t mq0B) {
+                                          uint32_t qdelta, uint32_t sslot, int32_t rec, uint32_t par, uint4 miA,
+                                          uint32_t mxA, uint4 miB, uint32_t mxB) {
   int32_t s1A, e1A, s1B, e1B;
   uint32_t jloA, UA, jloB, UB;
   const bool realA = seg_extent(A, wlen, s1A, e1A, jloA, UA) && wantA;  // clipped-away segments need no slot
@@ -365,8 +366,9 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
   const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
   const bool ok = idx + nseg <= (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
   if (ok) {
-    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, sslot, rec, miA, mq0A);
-    if (realB) write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, sslot, rec, miB, mq0B);
+    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, qdelta, sslot, rec, miA, mxA);
+    if (realB)
+      write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, qdelta, sslot, rec, miB, mxB);
   } else {
     for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
   }
@@ -389,14 +391,6 @@ struct UnitLoad {
   uint32_t ov32;
   uint32_t msh;                    // 0..1 mate qual byte shift | 2..6 4 * mate nibble shift
 };
-
-// Byte offsets, inside a record's payload, of the unit's first qual / first packed base.
-__device__ __forceinline__ void unit_offsets(uint32_t lseqnc, int32_t b0, int32_t& qoff, int32_t& soff) {
-  const uint32_t nc = lseqnc >> 16, lseq = lseqnc & 0xffffu;
-  const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
-  qoff = cigb + b0;
-  soff = cigb + (int32_t)(((lseq + 7) >> 3) * 8) + (b0 >> 1);
-}
 
 // Loads are issued unconditionally (inactive lanes read the start of the payload buffer) so
 // that every issue is the same number of VMEM instructions and the counted vmcnt waits stay
@@ -455,7 +449,8 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
     const bool mhas = in && (mi4.y & 0x40000u) != 0;
     const bool second = (mi4.y & 0x20000u) != 0;
     // mate read index of the unit's position 0
-    const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x + (int32_t)S.ex.s_mq0[s];
+    const uint32_t mx = S.ex.s_mx[s];
+    const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x + (int32_t)(mx & 0xffffu);
     uint32_t ov = 0;
     if (mhas) {
       const int32_t lo = (int32_t)mi4.x - (int32_t)(32u * jj), hi = lo + (int32_t)(mi4.y & 0xffffu);
@@ -468,8 +463,8 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
     L.meta |= second ? 0x40000u : 0u;
     const uint32_t mlseqnc = mi4.w;
     const int32_t mcig = (int32_t)((((mlseqnc >> 16) + 1u) & ~1u) * 4);
-    const int32_t qo = mcig + mi0;  // >= -23: the payload buffer starts with a pad
-    const int32_t so = mcig + (int32_t)((((mlseqnc & 0xffffu) + 7) >> 3) * 8) + (mi0 >> 1);
+    const int32_t qo = (int32_t)((mx >> 16) * 8u) + mi0;  // >= -23: the payload buffer starts with a pad
+    const int32_t so = mcig + (mi0 >> 1);
     L.msh = ((uint32_t)qo & 3u) | ((2u * ((uint32_t)so & 3u) + ((uint32_t)mi0 & 1u)) << 4);
     const uint8_t* mb = P.blob + (ov ? (uint64_t)mi4.z * 8 : 64);
     const uint8_t* mqp = mb + (ov ? (qo & ~3) : 0);
@@ -614,7 +609,7 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
             }
             const uint4 mi4 = B.ex.s_mate[sg];
             const int32_t mls = (int32_t)(mi4.w & 0xffffu);
-            const int32_t mi0 = Pw - (int32_t)mi4.x + (int32_t)B.ex.s_mq0[sg];
+            const int32_t mi0 = Pw - (int32_t)mi4.x + (int32_t)(B.ex.s_mx[sg] & 0xffffu);
             // (rare, so one rolled copy: unrolled it bloated the kernel past the instruction
             // cache and cost 4x)
 #pragma unroll 1
@@ -812,9 +807,10 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     // per-thread record cursor
     int32_t rec = r0 + tid;
     bool have = false, keep = false, prefetched = true, next_issued = false;
-    uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, sslot = 0, aux = 0, span = 0;
+    uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, qdelta = 0, sslot = 0, aux = 0, span = 0;
     uint32_t cg0 = 0, cg1 = 0, cg2 = 0;
     uint4 minfo = make_uint4(0, 0, 0, 0);
+    uint32_t mqd = 0;  // mate qdelta << 16
     int32_t rr = 0, qq = 0;
     int32_t rem_s = 0, rem_l = 0, rem_q = 0;  // stitch: rest of the M op being cut into pieces
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
@@ -841,6 +837,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         blob = c1.x;
         cg0 = c1.y; cg1 = c1.z; cg2 = c1.w;
         lseqnc = l_seq | (n_cigar << 16);
+        qdelta = c0.w >> 16;
         const int strand = strand_of((aux & AUX_MATE_SAME) != 0, flags);
         // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
         keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
@@ -850,6 +847,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
         sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
         minfo = make_uint4(0, 0, 0, 0);
+        mqd = 0;
         if constexpr (STITCH) {
           if (keep) {
             const int32_t m = P.mate[rec];
@@ -865,6 +863,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
               minfo.y = (m0.z >> 16) | ((maux & AUX_SIMPLE) ? 0x10000u : 0u) | ((uint32_t)(m & 1) << 17) | 0x40000u;  // bit 16: one M op
               minfo.z = m1.x;
               minfo.w = (m0.w & 0xffffu) | ((m0.z & 0xffffu) << 16);
+              mqd = m0.w & 0xffff0000u;
             }
           }
         }
@@ -883,10 +882,11 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         uint32_t cB = 0;              // cursor after the last segment taken
         int32_t rrB = 0, qqB = 0;
         uint4 miA = minfo, miB = minfo;
-        uint32_t mq0A = 0, mq0B = 0;
+        uint32_t mxA = 0, mxB = 0;  // mate: read index of the M op's first base | qdelta << 16
         int32_t rsB = 0, rlB = 0, rqB = 0;
         bool pieces = false;
         if constexpr (STITCH) pieces = (minfo.y & 0x50000u) == 0x40000u;  // mate with several CIGAR ops
+        mxA = mxB = mqd;
         if (more) {
           const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
           if (pieces) {
@@ -903,8 +903,8 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
                                  sB, lB, qB, msB, mlB, mqB);
             A.sref = sA; A.len = lA; A.q0 = qA;
             B.sref = sB; B.len = lB; B.q0 = qB;
-            miA.x = (uint32_t)msA; miA.y = (minfo.y & 0xffff0000u) | (uint32_t)mlA; mq0A = (uint32_t)mqA;
-            miB.x = (uint32_t)msB; miB.y = (minfo.y & 0xffff0000u) | (uint32_t)mlB; mq0B = (uint32_t)mqB;
+            miA.x = (uint32_t)msA; miA.y = (minfo.y & 0xffff0000u) | (uint32_t)mlA; mxA = mqd | (uint32_t)mqA;
+            miB.x = (uint32_t)msB; miB.y = (minfo.y & 0xffff0000u) | (uint32_t)mlB; mxB = mqd | (uint32_t)mqB;
             cB = c; rrB = r_; qqB = q_;
             rsB = rs; rlB = rl; rqB = rq;
             if (!wantA) more = false;
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         }
         if (!__any(wantA)) break;
-        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec, par, miA, mq0A, miB, mq0B);
+        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, qdelta, sslot, rec, par, miA, mxA, miB, mxB);
         if (wantA) {
           if (!ok) {
             failed = true;
@@ -1229,12 +1229,12 @@ __global__ void per_read_kernel(KernelParams P, const int32_t* iv_ref, int32_t n
     if (mi < 0) continue;
     const uint8_t* rb = P.blob + (uint64_t)c.blob * 8;
     const uint32_t cigb = ((c.n_cigar + 1u) & ~1u) * 4;
-    const uint32_t byte = rb[cigb + 8 * (((uint32_t)c.l_seq + 7) >> 3) + (mi >> 1)];
+    const uint32_t byte = rb[cigb + (mi >> 1)];
     const uint32_t nib = (mi & 1) ? (byte >> 4) : (byte & 15u);
     // Seq8ToEnumTable (pileup/common.go:66)
     const int e = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : 4;
     if (e == 4) continue;  // X is counted, never listed (pileup.go:239-240)
-    uint32_t q = rb[cigb + mi];
+    uint32_t q = rb[8u * c.qdelta + mi];
     if (P.clip > 0) q = clipped_qual(q, mi, (int32_t)c.l_seq, P.clip);
     if (q < (uint32_t)P.min_base_qual) continue;
     const unsigned long long o = off[4 * R + e] + cnt[e];

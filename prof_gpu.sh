@@ -15,7 +15,7 @@ for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout -s KILL 300 rocprofv3 --pmc $pmc --output-format csv -d $out/pmc$i -- python3 $R/bench.py $ARGS > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; }
+  timeout -s KILL 300 rocprofv3 --pmc $pmc --output-format csv -d $out/pmc$i -- python3 $R/bench.py $ARGS > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
 done
 cd $R
 python3 - "$out" <<'PY'

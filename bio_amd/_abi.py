@@ -70,7 +70,7 @@ EXPORTS = [
 HOST_EXPORTS = [
     "bio_pileup_default_opts", "bio_pileup_run", "bio_pileup_main", "bio_parse_region",
     "bio_parse_cols", "bio_bed_load", "bio_bed_endpoints", "bio_bed_intersects", "bio_bed_free",
-    "bio_fasta_seq8", "bio_bam_scan", "bio_bam_seek_scan",
+    "bio_fasta_seq8", "bio_bam_scan", "bio_bam_seek_scan", "bio_bam_write",
 ]
 
 
@@ -182,5 +182,8 @@ def load():
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
     lib.bio_bam_seek_scan.restype = C.c_int
+    lib.bio_bam_write.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
+                                  C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
+    lib.bio_bam_write.restype = C.c_int
     _lib = lib
     return lib

@@ -121,6 +121,10 @@ class BamIndex {
   std::vector<GEntry> g_;                   // .gbai entries, ascending (mapped first)
 };
 
+// Writes `b` as a BAM file (tools and tests; the driver only reads BAMs).
+std::string WriteBam(const std::string& path, const std::vector<std::string>& ref_names,
+                     const std::vector<int32_t>& ref_lens, const bp_record_batch& b, int level, int threads);
+
 // Integer value of a 2-character aux tag (A/c/C/s/S/i/I types); returns false if absent.
 bool AuxInt(const uint8_t* aux, uint32_t l_aux, const char tag[2], int64_t* out);
 

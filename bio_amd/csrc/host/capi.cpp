@@ -189,4 +189,18 @@ int bio_bam_seek_scan(const char* bam_path, const char* index_path, int32_t ref_
   return Ok(err, errlen);
 }
 
+int bio_bam_write(const char* path, int32_t n_ref, const char* const* ref_names, const int32_t* ref_lens,
+                  const bp_record_batch* batch, int32_t level, int32_t threads, char* err, size_t errlen) {
+  if (!path || !batch || n_ref < 0) return Fail("bio_bam_write: bad argument", err, errlen);
+  std::vector<std::string> names;
+  std::vector<int32_t> lens;
+  for (int32_t i = 0; i < n_ref; i++) {
+    names.push_back(Str(ref_names[i]));
+    lens.push_back(ref_lens[i]);
+  }
+  std::string m = bio::WriteBam(path, names, lens, *batch, level, threads);
+  if (!m.empty()) return Fail(m, err, errlen);
+  return Ok(err, errlen);
+}
+
 }  // extern "C"

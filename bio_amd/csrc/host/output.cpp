@@ -25,7 +25,8 @@ constexpr int kPerReadMask = kColEndDists | kColQuals | kColFraglens | kColStran
 // BC extra subfield and an empty EOF member), compressed a batch of blocks at a time.
 class Sink {
  public:
-  Sink(bool bgzf) : bgzf_(bgzf) {}
+  explicit Sink(bool bgzf, int level = Z_DEFAULT_COMPRESSION, int threads = 4)
+      : bgzf_(bgzf), level_(level), threads_(threads < 1 ? 1 : threads) {}
   ~Sink() { if (f_) fclose(f_); }
   std::string Open(const std::string& path) {
     path_ = path;
@@ -40,7 +41,7 @@ class Sink {
       return "";
     }
     pend_.append(p, n);
-    if (pend_.size() >= kBlock * kBatch) return Compress(false);
+    if (pend_.size() >= kBlock * kBatch * (size_t)threads_) return Compress(false);
     return "";
   }
   std::string Close() {
@@ -58,7 +59,7 @@ class Sink {
 
  private:
   static constexpr size_t kBlock = 0xff00;
-  static constexpr size_t kBatch = 32;
+  static constexpr size_t kBatch = 8;  // blocks per thread per batch
 
   std::string Compress(bool all) {
     size_t nblk = all ? (pend_.size() + kBlock - 1) / kBlock : pend_.size() / kBlock;
@@ -72,7 +73,7 @@ class Sink {
         o.resize(18 + compressBound((uLong)len) + 8);
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[b] = 1; continue; }
+        if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[b] = 1; continue; }
         zs.next_in = (Bytef*)pend_.data() + off;
         zs.avail_in = (uInt)len;
         zs.next_out = (Bytef*)o.data() + 18;
@@ -94,7 +95,7 @@ class Sink {
         o.resize(18 + clen + 8);
       }
     };
-    size_t nt = std::min<size_t>(4, nblk);
+    size_t nt = std::min<size_t>((size_t)threads_, nblk);
     if (nt == 1) {
       work(0, 1);
     } else {
@@ -111,6 +112,7 @@ class Sink {
   }
 
   bool bgzf_;
+  int level_, threads_;
   FILE* f_ = nullptr;
   std::string path_, pend_;
 };
@@ -378,6 +380,85 @@ class BasestrandTsvWriter : public RowWriter {
 };
 
 }  // namespace
+
+// BAM writer for tools and tests (SAM specification 4.2; the record block gbam.Unmarshal
+// decodes, encoding/bam/unmarshal.go:126-224): header, then the records of `b` in order.
+std::string WriteBam(const std::string& path, const std::vector<std::string>& ref_names,
+                     const std::vector<int32_t>& ref_lens, const bp_record_batch& b, int level, int threads) {
+  Sink out(true, level, threads);
+  std::string err = out.Open(path);
+  if (!err.empty()) return err;
+  std::string buf;
+  auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) buf.push_back((char)(v >> (8 * i))); };
+  auto put16 = [&](uint32_t v) { buf.push_back((char)v); buf.push_back((char)(v >> 8)); };
+  std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+  for (size_t i = 0; i < ref_names.size(); i++)
+    text += "@SQ\tSN:" + ref_names[i] + "\tLN:" + std::to_string(ref_lens[i]) + "\n";
+  buf += "BAM\1";
+  put32((uint32_t)text.size());
+  buf += text;
+  put32((uint32_t)ref_names.size());
+  for (size_t i = 0; i < ref_names.size(); i++) {
+    put32((uint32_t)ref_names[i].size() + 1);
+    buf += ref_names[i];
+    buf.push_back('\0');
+    put32((uint32_t)ref_lens[i]);
+  }
+  auto reg2bin = [](int64_t beg, int64_t end) -> uint32_t {
+    --end;
+    if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+  };
+  char tmp[32];
+  for (int64_t i = 0; i < b.n; i++) {
+    const char* nm = tmp;
+    size_t nl;
+    if (b.name && b.name_off) {
+      nm = (const char*)b.name + b.name_off[i];
+      nl = (size_t)(b.name_off[i + 1] - b.name_off[i]);
+    } else {
+      nl = (size_t)snprintf(tmp, sizeof tmp, "r%lld", (long long)i);
+    }
+    if (nl > 254) return "WriteBam: read name longer than 254 bytes";
+    const uint32_t nc = b.n_cigar[i], ls = b.l_seq[i];
+    const uint32_t* cg = b.cigar + b.cigar_off[i];
+    int64_t span = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+      const uint32_t op = cg[k] & 15u;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += cg[k] >> 4;
+    }
+    const uint32_t body = 32 + (uint32_t)nl + 1 + 4 * nc + (ls + 1) / 2 + ls;
+    put32(body);
+    put32((uint32_t)b.ref_id[i]);
+    put32((uint32_t)b.pos[i]);
+    buf.push_back((char)(nl + 1));
+    buf.push_back((char)b.mapq[i]);
+    put16(reg2bin(b.pos[i], b.pos[i] + (span > 0 ? span : 1)));
+    put16(nc);
+    put16(b.flags[i]);
+    put32(ls);
+    put32((uint32_t)b.mate_ref_id[i]);
+    put32((uint32_t)b.mate_pos[i]);
+    put32(0);
+    buf.append(nm, nl);
+    buf.push_back('\0');
+    buf.append((const char*)cg, 4 * (size_t)nc);
+    buf.append((const char*)b.seq + b.seq_off[i], (ls + 1) / 2);
+    buf.append((const char*)b.qual + b.qual_off[i], ls);
+    if (buf.size() >= (1u << 22)) {
+      err = out.Write(buf.data(), buf.size());
+      if (!err.empty()) return err;
+      buf.clear();
+    }
+  }
+  err = out.Write(buf.data(), buf.size());
+  if (!err.empty()) return err;
+  return out.Close();
+}
 
 std::unique_ptr<RowWriter> NewTsvWriter(const std::string& main_path, int col_bitset, bool bgzip,
                                         const std::vector<std::string>& ref_names,

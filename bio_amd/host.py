@@ -128,3 +128,14 @@ def bam_seek_scan(bam, index, ref_id, pos):
                              C.byref(sk), C.byref(af), e, len(e)):
         raise ValueError(e.value.decode())
     return bool(f.value), fr.value, fp.value, sk.value, af.value
+
+
+def bam_write(path, ref_names, ref_lens, batch, level=1, threads=8):
+    """Native BAM writer (fast path for tools; bamio.write_bam is the pure-Python one)."""
+    lib = _abi.load()
+    names = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+    lens = (C.c_int32 * len(ref_lens))(*[int(x) for x in ref_lens])
+    cb = batch.as_c()
+    e = _err()
+    if lib.bio_bam_write(path.encode(), len(ref_names), names, lens, C.byref(cb), level, threads, e, len(e)):
+        raise ValueError(e.value.decode())

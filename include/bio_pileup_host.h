@@ -11,6 +11,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "bio_pileup.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -86,6 +88,12 @@ int bio_bam_scan(const char* path, int64_t* n_records, int64_t* sum_l_seq, int64
 int bio_bam_seek_scan(const char* bam_path, const char* index_path, int32_t ref_id, int32_t pos,
                       int32_t* found, int32_t* first_ref, int32_t* first_pos, int64_t* n_skipped,
                       int64_t* n_at_or_after, char* err, size_t errlen);
+
+/* Writes the records of `batch` (coordinate-sorted; names optional) as a BAM file: BGZF at
+ * zlib `level`, compressed on `threads` threads.  No counterpart on the reference's pileup
+ * path (which only reads BAMs): input generator for tools and tests. */
+int bio_bam_write(const char* path, int32_t n_ref, const char* const* ref_names, const int32_t* ref_lens,
+                  const bp_record_batch* batch, int32_t level, int32_t threads, char* err, size_t errlen);
 
 #ifdef __cplusplus
 }

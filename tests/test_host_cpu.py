@@ -177,6 +177,24 @@ def test_bam_reader_decodes_every_record(tmp_path):
     assert batch.n * 300 > 2 * 0xFF00  # spans several BGZF blocks
 
 
+def test_native_bam_writer_round_trip(tmp_path):
+    path, batch = _small_bam(tmp_path)
+    native = str(tmp_path / "n.bam")
+    host.bam_write(native, ["chrT"], [20000], batch, level=1, threads=3)
+    assert host.bam_scan(native) == host.bam_scan(path)
+    # same inflated bytes as the pure-Python writer (header and records)
+    import zlib
+
+    def inflate(p):
+        raw, out, o = open(p, "rb").read(), b"", 0
+        while o < len(raw):
+            bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+            out += zlib.decompress(raw[o + 18:o + bsize - 8], -15)
+            o += bsize
+        return out
+    assert inflate(native) == inflate(path)
+
+
 def test_bam_reader_rejects_corruption(tmp_path):
     path, _ = _small_bam(tmp_path, n=400)
     raw = bytearray(open(path, "rb").read())

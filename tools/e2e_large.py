@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end run at whole-contig scale: synthetic 30x reads over L Mb -> BAM (native writer) +
+FASTA -> bio-pileup -> files; prints the driver's BIO_PILEUP_STATS line and wall times.
+Secondary measurement, not a bench line.  Usage: e2e_large.py [Mb=60] [format=basestrand-tsv]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bio_amd import bamio, host, synth  # noqa: E402
+
+mb = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+fmt = sys.argv[2] if len(sys.argv) > 2 else "basestrand-tsv"
+extra = sys.argv[3:]
+L = int(mb * 1e6)
+d = tempfile.mkdtemp(dir=os.environ.get("E2E_TMP", "/tmp"))
+t0 = time.time()
+sb = synth.generate([(0, 0, L - 1000, 30.0)], with_names=True, threads=16)
+rb = sb.to_record_batch()
+bam = os.path.join(d, "in.bam")
+host.bam_write(bam, ["chr1"], [L], rb, level=1, threads=16)
+rng = np.random.default_rng(1)
+fa = os.path.join(d, "ref.fa")
+seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
+with open(fa, "wb") as f:
+    f.write(b">chr1\n")
+    lines = seq[: L // 60 * 60].reshape(-1, 60)
+    out = np.empty((lines.shape[0], 61), np.uint8)
+    out[:, :60] = lines
+    out[:, 60] = 10
+    f.write(out.tobytes())
+    if L % 60:
+        f.write(seq[L // 60 * 60:].tobytes() + b"\n")
+bed = os.path.join(d, "all.bed")
+bamio.write_bed(bed, [(0, 0, L)], ["chr1"])
+print(f"inputs: {rb.n} records, BAM {os.path.getsize(bam) / 1e9:.2f} GB, FASTA {L / 1e6:.0f} Mb "
+      f"(made in {time.time() - t0:.0f} s)", flush=True)
+n = rb.n
+sb.close()
+del rb
+exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
+env = dict(os.environ, BIO_PILEUP_STATS="1")
+t0 = time.time()
+r = subprocess.run([exe, "-bed", bed, "-format", fmt, *extra, "-out", os.path.join(d, "o"), bam, fa],
+                   capture_output=True, text=True, env=env)
+wall = time.time() - t0
+print(r.stderr.strip()[-600:], flush=True)
+outs = [p for p in os.listdir(d) if p.startswith("o.")]
+size = sum(os.path.getsize(os.path.join(d, p)) for p in outs)
+print(f"bio-pileup -bed all -format {fmt} {' '.join(extra)}: rc {r.returncode}, {wall:.1f} s wall, "
+      f"{n / wall / 1e6:.2f} M records/s, output {size / 1e9:.2f} GB in {outs}", flush=True)
+for p in [bam, fa, bed] + [os.path.join(d, p) for p in outs]:
+    os.remove(p)
+os.rmdir(d)
+sys.exit(r.returncode)

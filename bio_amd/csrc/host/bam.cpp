@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <future>
 #include <thread>
 
 #include "bio_host.h"
@@ -46,49 +47,55 @@ inline uint32_t U32(const uint8_t* p) {
 inline int32_t I32(const uint8_t* p) { return (int32_t)U32(p); }
 
 constexpr int kBatchBlocks = 256;  // up to 16 MiB inflated per refill
-constexpr int kInflateThreads = 4;
 }  // namespace
 
 struct BamReader::Impl {
   FILE* f = nullptr;
-  bool file_eof = false;
+  bool file_eof = false;     // the batch reader met the end of the file
   std::vector<uint8_t> buf;  // inflated bytes not yet consumed: [rd, buf.size())
   size_t rd = 0;
-  std::vector<uint8_t> raw;  // compressed batch
-  struct Blk { size_t off, clen, isize, out; };
-  std::vector<Blk> blks;
   uint64_t file_pos = 0;  // file offset of the next byte fread returns
   // (offset in buf, file offset) of the blocks buf holds bytes of, ascending
   std::vector<std::pair<size_t, uint64_t>> marks;
 
-  ~Impl() { if (f) fclose(f); }
+  // One batch of BGZF blocks, read and inflated off the main thread while the records of the
+  // previous batch are decoded.
+  struct Batch {
+    std::vector<uint8_t> data;
+    std::vector<std::pair<size_t, uint64_t>> marks;  // (offset in data, file offset)
+    bool eof = false;
+    uint64_t end_pos = 0;  // file offset behind the batch
+    std::string err;
+  };
+  std::future<std::unique_ptr<Batch>> next;
 
-  // Reads and inflates the next batch of BGZF blocks behind the unconsumed tail.
-  std::string Refill() {
-    if (rd > 0) {
-      buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)rd);
-      // keep the mark of the block the tail starts in (its offset becomes 0) and later ones
-      size_t k = 0;
-      while (k + 1 < marks.size() && marks[k + 1].first <= rd) k++;
-      marks.erase(marks.begin(), marks.begin() + (ptrdiff_t)k);
-      for (auto& mk : marks) mk.first = mk.first > rd ? mk.first - rd : 0;
-      rd = 0;
-    }
-    raw.clear();
-    blks.clear();
-    size_t out_total = buf.size();
-    while (!file_eof && (int)blks.size() < kBatchBlocks) {
+  ~Impl() {
+    if (next.valid()) next.wait();
+    if (f) fclose(f);
+  }
+
+  std::unique_ptr<Batch> ReadBatch(uint64_t at) {
+    std::unique_ptr<Batch> out(new Batch);
+    Batch& B = *out;
+    struct Blk { size_t off, clen, isize, out; };
+    std::vector<Blk> blks;
+    std::vector<uint8_t> raw;
+    size_t out_total = 0;
+    uint64_t pos = at;
+    while ((int)blks.size() < kBatchBlocks) {
       uint8_t hd[18];
-      const uint64_t block_at = file_pos;
+      const uint64_t block_at = pos;
       size_t got = fread(hd, 1, 18, f);
-      if (got == 0) { file_eof = true; break; }
-      if (got != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4))
-        return "bgzf: invalid block header";
+      if (got == 0) { B.eof = true; break; }
+      if (got != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) {
+        B.err = "bgzf: invalid block header";
+        return out;
+      }
       unsigned xlen = U16(hd + 10);
       // The BC subfield is first in every BGZF writer in use; handle the general case too.
       std::vector<uint8_t> extra(xlen);
       memcpy(extra.data(), hd + 12, std::min<size_t>(6, xlen));
-      if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) return "bgzf: truncated block";
+      if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) { B.err = "bgzf: truncated block"; return out; }
       int bsize = -1;
       for (size_t p = 0; p + 4 <= extra.size();) {
         unsigned slen = U16(extra.data() + p + 2);
@@ -96,23 +103,24 @@ struct BamReader::Impl {
           bsize = U16(extra.data() + p + 4);
         p += 4 + slen;
       }
-      if (bsize < 0) return "bgzf: missing BC subfield";
+      if (bsize < 0) { B.err = "bgzf: missing BC subfield"; return out; }
       long total = (long)bsize + 1;
       long remaining = total - 12 - (long)xlen;  // deflate data + crc32 + isize
-      if (xlen < 6 || remaining < 8) return "bgzf: invalid block size";
+      if (xlen < 6 || remaining < 8) { B.err = "bgzf: invalid block size"; return out; }
       size_t off = raw.size();
       raw.resize(off + (size_t)remaining);
-      if (fread(raw.data() + off, 1, (size_t)remaining, f) != (size_t)remaining) return "bgzf: truncated block";
+      if (fread(raw.data() + off, 1, (size_t)remaining, f) != (size_t)remaining) { B.err = "bgzf: truncated block"; return out; }
       size_t isize = U32(raw.data() + off + (size_t)remaining - 4);
-      if (isize > 65536) return "bgzf: invalid uncompressed size";
+      if (isize > 65536) { B.err = "bgzf: invalid uncompressed size"; return out; }
       blks.push_back({off, (size_t)remaining - 8, isize, out_total});
-      if (isize) marks.emplace_back(out_total, block_at);
-      file_pos = block_at + (uint64_t)total;
+      if (isize) B.marks.emplace_back(out_total, block_at);
+      pos = block_at + (uint64_t)total;
       out_total += isize;
     }
-    buf.resize(out_total);
-    if (blks.empty()) return "";
-    int nt = std::min<int>(kInflateThreads, (int)blks.size());
+    B.end_pos = pos;
+    B.data.resize(out_total);
+    if (blks.empty()) return out;
+    int nt = std::min<int>(HostThreads(), (int)blks.size());
     std::vector<int> bad((size_t)nt, 0);
     auto work = [&](int t) {
       z_stream zs;
@@ -123,12 +131,12 @@ struct BamReader::Impl {
         if (inflateInit2(&zs, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
         zs.next_in = raw.data() + b.off;
         zs.avail_in = (uInt)b.clen;
-        zs.next_out = buf.data() + b.out;
+        zs.next_out = B.data.data() + b.out;
         zs.avail_out = (uInt)b.isize;
         int rc = inflate(&zs, Z_FINISH);
         inflateEnd(&zs);
         if (rc != Z_STREAM_END || zs.avail_out != 0) { bad[(size_t)t] = 1; return; }
-        uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), buf.data() + b.out, (uInt)b.isize);
+        uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), B.data.data() + b.out, (uInt)b.isize);
         if (crc != U32(raw.data() + b.off + b.clen)) { bad[(size_t)t] = 1; return; }
       }
     };
@@ -140,7 +148,33 @@ struct BamReader::Impl {
       for (auto& x : th) x.join();
     }
     for (int b : bad)
-      if (b) return "bgzf: corrupt block (inflate or CRC failure)";
+      if (b) { B.err = "bgzf: corrupt block (inflate or CRC failure)"; break; }
+    return out;
+  }
+
+  // Appends the next batch behind the unconsumed tail and starts reading the one after it.
+  std::string Refill() {
+    if (rd > 0) {
+      buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)rd);
+      // keep the mark of the block the tail starts in (its offset becomes 0) and later ones
+      size_t k = 0;
+      while (k + 1 < marks.size() && marks[k + 1].first <= rd) k++;
+      marks.erase(marks.begin(), marks.begin() + (ptrdiff_t)k);
+      for (auto& mk : marks) mk.first = mk.first > rd ? mk.first - rd : 0;
+      rd = 0;
+    }
+    if (file_eof) return "";
+    std::unique_ptr<Batch> b = next.valid() ? next.get() : ReadBatch(file_pos);
+    if (!b->err.empty()) return b->err;
+    const size_t base = buf.size();
+    buf.insert(buf.end(), b->data.begin(), b->data.end());
+    for (const auto& mk : b->marks) marks.emplace_back(base + mk.first, mk.second);
+    file_pos = b->end_pos;
+    file_eof = b->eof;
+    if (!file_eof) {
+      const uint64_t at = file_pos;
+      next = std::async(std::launch::async, [this, at] { return ReadBatch(at); });
+    }
     return "";
   }
 
@@ -187,6 +221,7 @@ std::string BamReader::Open(const std::string& path) {
 std::string BamReader::Seek(uint64_t voffset) {
   Impl& m = *impl_;
   const uint64_t coff = voffset >> 16;
+  if (m.next.valid()) m.next.get();  // the reader thread owns the file until its batch is done
   if (fseeko(m.f, (off_t)coff, SEEK_SET) != 0) return "bgzf: seek failed";
   m.file_pos = coff;
   m.file_eof = false;

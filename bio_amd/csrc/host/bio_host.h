@@ -121,6 +121,12 @@ class BamIndex {
   std::vector<GEntry> g_;                   // .gbai entries, ascending (mapped first)
 };
 
+// Host worker threads for inflate, rendering and output compression: -parallelism when
+// given (the reference's default is every CPU, pileup.go:56-68), else the CPUs of this
+// process capped at 16.
+int HostThreads();
+void SetHostThreads(int n);
+
 // Writes `b` as a BAM file (tools and tests; the driver only reads BAMs).
 std::string WriteBam(const std::string& path, const std::vector<std::string>& ref_names,
                      const std::vector<int32_t>& ref_lens, const bp_record_batch& b, int level, int threads);

@@ -72,7 +72,7 @@ int BioPileupMain(int argc, char** argv) {
       {"min-bag-depth", Flag::kInt, &o.MinBagDepth, "Lower bound on bag depth (DS aux tag value)"},
       {"min-base-qual", Flag::kInt, &o.MinBaseQual, "Lower bound on base quality in a single read"},
       {"out", Flag::kString, &out_prefix, "Output path prefix"},
-      {"parallelism", Flag::kInt, &o.Parallelism, "Accepted for compatibility; jobs run on the GPU"},
+      {"parallelism", Flag::kInt, &o.Parallelism, "Host threads for inflate, text rendering and output compression (0 = CPUs, at most 16); jobs run on the GPU"},
       {"per-strand", Flag::kBool, &o.PerStrand, "Generate two pairs of output files, one for each strand"},
       {"remove-sq", Flag::kBool, &o.RemoveSq, "Remove sequencing duplicates (no DL aux tag with value > 1)"},
       {"stitch", Flag::kBool, &o.Stitch, "Stitch read-pairs"},

@@ -117,52 +117,79 @@ class Sink {
   std::string path_, pend_;
 };
 
-// tsv.Writer restatement over a Sink.
-class Tsv {
+// tsv.Writer restatement: the formatting half works on a string, so that rows can be rendered
+// on several threads and appended to the file in order.
+class TsvBuf {
  public:
-  Tsv(bool bgzf) : sink_(bgzf) { buf_.reserve(kFlush + 4096); }
-  std::string Open(const std::string& path) { return sink_.Open(path); }
   void WriteString(const char* s, size_t n) { buf_.append(s, n); buf_.push_back('\t'); }
   void WriteString(const std::string& s) { WriteString(s.data(), s.size()); }
   void WriteByte(char c) { buf_.push_back(c); buf_.push_back('\t'); }
-  void WriteUint32(uint32_t v) {
-    char t[12];
-    int n = 0;
-    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) buf_.push_back(t[--n]);
-    buf_.push_back('\t');
-  }
+  void WriteUint32(uint32_t v) { AppendUint(v); buf_.push_back('\t'); }
   void WritePartial(const char* s, size_t n) { buf_.append(s, n); }
-  void WriteCsvUint32(uint32_t v) {
-    char t[12];
-    int n = 0;
-    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) buf_.push_back(t[--n]);
-    buf_.push_back(',');
-  }
+  void WriteCsvUint32(uint32_t v) { AppendUint(v); buf_.push_back(','); }
   void WriteCsvByte(char c) { buf_.push_back(c); buf_.push_back(','); }
   void EndCsv() { if (!buf_.empty() && buf_.back() == ',') buf_.back() = '\t'; }
-  std::string EndLine() {
-    if (!buf_.empty() && buf_.back() == '\t') buf_.back() = '\n'; else buf_.push_back('\n');
-    if (buf_.size() >= kFlush) return Flush();
-    return "";
-  }
-  std::string Flush() {
-    std::string err = sink_.Write(buf_.data(), buf_.size());
-    buf_.clear();
-    return err;
-  }
-  std::string Close() {
-    std::string err = Flush();
-    std::string e2 = sink_.Close();
-    return err.empty() ? e2 : err;
-  }
+  void EndLine() { if (!buf_.empty() && buf_.back() == '\t') buf_.back() = '\n'; else buf_.push_back('\n'); }
+  std::string& str() { return buf_; }
 
  private:
-  static constexpr size_t kFlush = 1 << 20;
-  Sink sink_;
+  void AppendUint(uint32_t v) {
+    char t[12];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) buf_.push_back(t[--n]);
+  }
   std::string buf_;
 };
+
+// One output file: header lines go through line(), rendered row text through Append().
+class Tsv {
+ public:
+  Tsv(bool bgzf) : sink_(bgzf, Z_DEFAULT_COMPRESSION, HostThreads()) {}
+  std::string Open(const std::string& path) { return sink_.Open(path); }
+  TsvBuf& line() { return line_; }
+  std::string EndLine() {
+    line_.EndLine();
+    std::string err = sink_.Write(line_.str().data(), line_.str().size());
+    line_.str().clear();
+    return err;
+  }
+  std::string Append(const std::string& text) { return sink_.Write(text.data(), text.size()); }
+  std::string Close() { return sink_.Close(); }
+
+ private:
+  Sink sink_;
+  TsvBuf line_;
+};
+
+// Renders rows [0, n) in tasks of kRenderRows on HostThreads() threads; `render(first, last,
+// task_slot)` fills the slot's buffers, `emit(task_slot)` appends them to the files in order.
+constexpr int64_t kRenderRows = 16384;
+template <class Render, class Emit>
+std::string RenderParallel(int64_t n, int n_slots, Render render, Emit emit) {
+  const int64_t n_tasks = (n + kRenderRows - 1) / kRenderRows;
+  for (int64_t t0 = 0; t0 < n_tasks; t0 += n_slots) {
+    const int m = (int)std::min<int64_t>(n_slots, n_tasks - t0);
+    std::vector<std::string> errs((size_t)m);
+    auto work = [&](int k) {
+      const int64_t first = (t0 + k) * kRenderRows;
+      errs[(size_t)k] = render(first, std::min(n, first + kRenderRows), k);
+    };
+    if (m == 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> th;
+      for (int k = 0; k < m; k++) th.emplace_back(work, k);
+      for (auto& x : th) x.join();
+    }
+    for (int k = 0; k < m; k++) {
+      if (!errs[(size_t)k].empty()) return errs[(size_t)k];
+      std::string e = emit(k);
+      if (!e.empty()) return e;
+    }
+  }
+  return "";
+}
 
 struct RefLookup {
   const std::vector<std::string>& names;
@@ -188,25 +215,25 @@ class TsvWriter : public RowWriter {
     if (!err.empty()) return err;
     err = alt_.Open(main_path + ".alt.tsv" + (bgz ? ".gz" : ""));
     if (!err.empty()) return err;
-    ref_.WriteString("#CHROM\tPOS\tREF");
-    alt_.WriteString("#CHROM\tPOS\tREF\tALT");
-    if (cols_ & kColDpRef) ref_.WriteString("DP");
-    if (cols_ & kColDpAlt) alt_.WriteString("DP");
+    ref_.line().WriteString("#CHROM\tPOS\tREF");
+    alt_.line().WriteString("#CHROM\tPOS\tREF\tALT");
+    if (cols_ & kColDpRef) ref_.line().WriteString("DP");
+    if (cols_ & kColDpAlt) alt_.line().WriteString("DP");
     if (cols_ & kColEndDists) {  // output.go:93-114
-      ref_.WriteString("5P_DISTS\t3P_DISTS"); alt_.WriteString("5P_DISTS\t3P_DISTS");
+      ref_.line().WriteString("5P_DISTS\t3P_DISTS"); alt_.line().WriteString("5P_DISTS\t3P_DISTS");
       empty_ += ".\t.\t";
     }
-    if (cols_ & kColQuals) { ref_.WriteString("QUALS"); alt_.WriteString("QUALS"); empty_ += ".\t"; }
-    if (cols_ & kColFraglens) { ref_.WriteString("FRAGLENS"); alt_.WriteString("FRAGLENS"); empty_ += ".\t"; }
-    if (cols_ & kColStrands) { ref_.WriteString("STRANDS"); alt_.WriteString("STRANDS"); empty_ += ".\t"; }
-    if (cols_ & kColHighQ) { ref_.WriteString("ref_depth_tier1"); alt_.WriteString("alt_depth_tier1"); }
-    if (cols_ & kColLowQ) { ref_.WriteString("ref_depth_tier2"); alt_.WriteString("alt_depth_tier2"); }
+    if (cols_ & kColQuals) { ref_.line().WriteString("QUALS"); alt_.line().WriteString("QUALS"); empty_ += ".\t"; }
+    if (cols_ & kColFraglens) { ref_.line().WriteString("FRAGLENS"); alt_.line().WriteString("FRAGLENS"); empty_ += ".\t"; }
+    if (cols_ & kColStrands) { ref_.line().WriteString("STRANDS"); alt_.line().WriteString("STRANDS"); empty_ += ".\t"; }
+    if (cols_ & kColHighQ) { ref_.line().WriteString("ref_depth_tier1"); alt_.line().WriteString("alt_depth_tier1"); }
+    if (cols_ & kColLowQ) { ref_.line().WriteString("ref_depth_tier2"); alt_.line().WriteString("alt_depth_tier2"); }
     err = ref_.EndLine();
     if (!err.empty()) return err;
     return alt_.EndLine();
   }
   // per-read columns of one feature list (output.go:173-200, :235-262)
-  void WriteLists(Tsv& w, const bp_per_read* f, uint64_t m) {
+  void WriteLists(TsvBuf& w, const bp_per_read* f, uint64_t m) const {
     if (cols_ & kColEndDists) {
       for (uint64_t k = 0; k < m; k++) w.WriteCsvUint32(f[k].dist5p);
       w.EndCsv();
@@ -228,10 +255,27 @@ class TsvWriter : public RowWriter {
   }
   std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                     const uint64_t* off, const bp_per_read* feats) override {
-    std::string err;
     const bool per_read = (cols_ & kPerReadMask) != 0;
     if (per_read && (!off || (!feats && off[4 * n] != off[0]))) return "pileup output: per-read columns without feature lists";
-    for (int64_t i = 0; i < n; i++) {
+    const int n_slots = HostThreads();
+    std::vector<TsvBuf> rb((size_t)n_slots), ab((size_t)n_slots);
+    return RenderParallel(
+        n, n_slots,
+        [&](int64_t first, int64_t last, int k) {
+          rb[(size_t)k].str().clear();
+          ab[(size_t)k].str().clear();
+          return Render(ref_id, pos, vals, first, last, off, feats, rb[(size_t)k], ab[(size_t)k]);
+        },
+        [&](int k) {
+          std::string e = ref_.Append(rb[(size_t)k].str());
+          return e.empty() ? alt_.Append(ab[(size_t)k].str()) : e;
+        });
+  }
+  std::string Render(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t first, int64_t last,
+                     const uint64_t* off, const bp_per_read* feats, TsvBuf& ref_, TsvBuf& alt_) const {
+    std::string err;
+    const bool per_read = (cols_ & kPerReadMask) != 0;
+    for (int64_t i = first; i < last; i++) {
       const uint32_t* v = vals + i * BP_ROW_U32;
       uint8_t b8;
       err = lk_.Get(ref_id[i], pos[i], &b8);
@@ -250,8 +294,7 @@ class TsvWriter : public RowWriter {
       }
       if (cols_ & kColHighQ) ref_.WriteUint32(v[1 + 2 * ref_base] + v[2 + 2 * ref_base]);
       if (cols_ & kColLowQ) ref_.WriteByte('0');
-      err = ref_.EndLine();
-      if (!err.empty()) return err;
+      ref_.EndLine();
       for (int alt = 0; alt < 5; alt++) {
         if (alt == ref_base) continue;
         const uint32_t c = v[1 + 2 * alt] + v[2 + 2 * alt];
@@ -267,8 +310,7 @@ class TsvWriter : public RowWriter {
         }
         if (cols_ & kColHighQ) alt_.WriteUint32(c);
         if (cols_ & kColLowQ) alt_.WriteByte('0');
-        err = alt_.EndLine();
-        if (!err.empty()) return err;
+        alt_.EndLine();
       }
     }
     return "";
@@ -293,7 +335,7 @@ class BasestrandTsvWriter : public RowWriter {
   std::string Open(const std::string& main_path, bool bgz) {
     std::string err = w_.Open(main_path + ".basestrand.tsv" + (bgz ? ".gz" : ""));
     if (!err.empty()) return err;
-    w_.WriteString("#CHROM\tPOS\tREF\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-");
+    w_.line().WriteString("#CHROM\tPOS\tREF\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-");
     // The per-read header pieces start with a tab AND go through WriteString (output.go:
     // 405-418), which appends one: restated literally, so the header carries an empty column
     // before each piece.  grailbio/base/tsv is not in the reference tree: parity unpinned.
@@ -304,7 +346,7 @@ class BasestrandTsvWriter : public RowWriter {
         if (!pre) continue;
         for (int k = 0; k < 8; k++) h += std::string("\t") + pre + "_" + kBS[k];
       }
-      w_.WriteString(h);
+      w_.line().WriteString(h);
       for (const char* pre : {a, b})
         if (pre) for (int k = 0; k < 8; k++) empty_ += ".\t";
     };
@@ -317,7 +359,8 @@ class BasestrandTsvWriter : public RowWriter {
   // one per-read column group over the four bases (output.go:463-552): values of forward-strand
   // reads go to the + column, all others to the - column
   template <class F>
-  void WriteGroup(const uint64_t* off4, const bp_per_read* feats, uint64_t base0, F value) {
+  static void WriteGroup(TsvBuf& w_, std::string& plus_, std::string& minus_, const uint64_t* off4,
+                         const bp_per_read* feats, uint64_t base0, F value) {
     for (int b = 0; b < 4; b++) {
       const uint64_t m = off4[b + 1] - off4[b];
       if (m == 0) { w_.WriteString(".\t."); continue; }
@@ -332,10 +375,23 @@ class BasestrandTsvWriter : public RowWriter {
   static void AppendUint(std::string& s, uint32_t v) { s += std::to_string(v); s.push_back(','); }
   std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                     const uint64_t* off, const bp_per_read* feats) override {
-    std::string err;
     const bool per_read = (cols_ & kPerReadMask) != 0;
     if (per_read && (!off || (!feats && off[4 * n] != off[0]))) return "pileup output: per-read columns without feature lists";
-    for (int64_t i = 0; i < n; i++) {
+    const int n_slots = HostThreads();
+    std::vector<TsvBuf> tb((size_t)n_slots);
+    return RenderParallel(
+        n, n_slots,
+        [&](int64_t first, int64_t last, int k) {
+          tb[(size_t)k].str().clear();
+          return Render(ref_id, pos, vals, first, last, off, feats, tb[(size_t)k]);
+        },
+        [&](int k) { return w_.Append(tb[(size_t)k].str()); });
+  }
+  std::string Render(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t first, int64_t last,
+                     const uint64_t* off, const bp_per_read* feats, TsvBuf& w_) const {
+    std::string err, plus_, minus_;
+    const bool per_read = (cols_ & kPerReadMask) != 0;
+    for (int64_t i = first; i < last; i++) {
       const uint32_t* v = vals + i * BP_ROW_U32;
       uint8_t b8;
       err = lk_.Get(ref_id[i], pos[i], &b8);
@@ -350,23 +406,22 @@ class BasestrandTsvWriter : public RowWriter {
         } else {
           const uint64_t* o4 = off + 4 * i;
           if (cols_ & kColEndDists) {
-            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.dist5p); });
-            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) {
+            WriteGroup(w_, plus_, minus_, o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.dist5p); });
+            WriteGroup(w_, plus_, minus_, o4, feats, off[0], [](const bp_per_read& f, std::string& s) {
               AppendUint(s, (uint16_t)(f.fraglen - 1 - f.dist5p));
             });
           }
           if (cols_ & kColQuals)
-            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.qual); });
+            WriteGroup(w_, plus_, minus_, o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.qual); });
           if (cols_ & kColFraglens)
-            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.fraglen); });
+            WriteGroup(w_, plus_, minus_, o4, feats, off[0], [](const bp_per_read& f, std::string& s) { AppendUint(s, f.fraglen); });
           if (cols_ & kColStrands)
-            WriteGroup(o4, feats, off[0], [](const bp_per_read& f, std::string& s) {
+            WriteGroup(w_, plus_, minus_, o4, feats, off[0], [](const bp_per_read& f, std::string& s) {
               s += f.strand == 1 ? "+," : "-,";
             });
         }
       }
-      err = w_.EndLine();
-      if (!err.empty()) return err;
+      w_.EndLine();
     }
     return "";
   }
@@ -376,10 +431,18 @@ class BasestrandTsvWriter : public RowWriter {
   int cols_;
   Tsv w_;
   RefLookup lk_;
-  std::string empty_, plus_, minus_;
+  std::string empty_;
 };
 
 }  // namespace
+
+static int g_host_threads = 0;
+int HostThreads() {
+  if (g_host_threads > 0) return g_host_threads;
+  unsigned hc = std::thread::hardware_concurrency();
+  return (int)std::max<unsigned>(1, std::min<unsigned>(hc ? hc : 1, 16));
+}
+void SetHostThreads(int n) { g_host_threads = n > 0 ? std::min(n, 256) : 0; }
 
 // BAM writer for tools and tests (SAM specification 4.2; the record block gbam.Unmarshal
 // decodes, encoding/bam/unmarshal.go:126-224): header, then the records of `b` in order.

@@ -317,6 +317,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     // the reference panics at the first pair it merges (pileup.go:422-443); refused up front
     return "stitched per-read features not yet supported";
   if (bp_init(opts.Device) != BP_OK) return bp_last_error(nullptr);
+  SetHostThreads(opts.Parallelism);
 
   Driver drv(opts, hd, bed, tsv_format ? 1 : 0);
   drv.per_read = per_read;

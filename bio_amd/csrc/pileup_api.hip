@@ -678,7 +678,7 @@ constexpr int32_t kSliceRecs = 2048;  // records per slice of a deep window
 // span can reach.
 static int64_t item_capacity(const bp_handle* h) {
   const int64_t per_rec = (int64_t)h->max_span / window_size() + 2;
-  return per_rec * (h->n_reads / kSliceRecs + 1) + 16;
+  return per_rec * (2 * h->n_reads / kSliceRecs + 1) + 16;  // a sliced window has more than kSliceRecs records: <= 2n/kSliceRecs slices
 }
 
 // Kernel arguments for the handle's resident job.

@@ -92,9 +92,10 @@ struct KernelParams {
   uint32_t* rows;             // n_rows * 11
   DeviceError* err;
   const uint8_t* qthr;        // [96] stitch: qthr[q0] = smallest q1 with qualSum[q0][q1] >= minBaseQual (255: none)
-  // Deep windows (more than 2*slice_recs records) are cut into slices of slice_recs records:
-  // the window's own work item keeps the first slice, the plan kernel appends the others
-  // here as (window, first record, end record, 0) and a second launch adds them to the rows.
+  // Deep windows (more than slice_recs records) are cut into even slices of at most
+  // slice_recs records: the plan kernel appends them here as (window, first record, end
+  // record, 0), the first launch writes the window's rows as zeros, and a second launch adds
+  // the slices to them.
   uint4* extra_items;
   uint32_t* n_extra;          // number of appended items (device counter, reset per compute)
   int32_t extra_cap;

@@ -142,21 +142,23 @@ __global__ void plan_windows_kernel(KernelParams P, int32_t* win_r0, int32_t* wi
   const int64_t a = first_at_or_after(P, r0, hi, win.g1);
   win_r0[w] = (int32_t)r0;
   int64_t r1 = a;
-  // a deep window keeps its first slice; the rest become extra work items
+  // a deep window is cut into even slices of at most slice_recs records, all of them extra
+  // work items for the second launch; the first launch only writes its rows (zeros)
   const int64_t n = r1 - r0, sl = P.slice_recs;
-  if (P.extra_items && n > 2 * sl) {
-    const uint32_t cnt = (uint32_t)((n - sl + sl - 1) / sl);
+  if (P.extra_items && n > sl) {
+    const uint32_t cnt = (uint32_t)((n + sl - 1) / sl);
+    const int64_t each = (n + cnt - 1) / cnt;
     const uint32_t base = atomicAdd(P.n_extra, cnt);
     for (uint32_t k = 0; k < cnt; k++) {
       if (base + k >= (uint32_t)P.extra_cap) {
         P.err->kind = ERR_ITEM_OVERFLOW;
         break;
       }
-      const int64_t s0 = r0 + sl * (int64_t)(k + 1);
-      const int64_t s1 = s0 + sl < r1 ? s0 + sl : r1;
+      const int64_t s0 = r0 + each * (int64_t)k;
+      const int64_t s1 = s0 + each < r1 ? s0 + each : r1;
       P.extra_items[base + k] = make_uint4((uint32_t)w, (uint32_t)s0, (uint32_t)s1, 0u);
     }
-    r1 = r0 + sl;
+    r1 = r0;
   }
   win_r1[w] = (int32_t)r1;
 }
@@ -494,7 +496,7 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
 // found its mate decides them from both reads (equal bases: qualSumTable threshold, else X).
 template <bool STITCH, bool CLIP, bool MINQ0>
 __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
-                                                   const UnitLoad<STITCH || !MINQ0, STITCH>& L) {
+                                                   const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t cpo) {
   static_assert(!(STITCH && MINQ0), "the stitched path always reads the quals");
   constexpr uint32_t M1 = 0x11111111u;
   const uint32_t meta = L.meta;
@@ -503,7 +505,7 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
   const uint32_t ov32 = L.ov32;
   const uint32_t* const x = L.sd;  // base k of a dword at bits 4k (the packer stores it that way)
   const uint32_t nsh = (meta >> 4) & 0x1cu;  // 4 * nibble shift
-  const uint32_t cbase = (jj + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
+  const uint32_t cbase = (jj + cpo + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
   char* const lds = (char*)B.cnt;
 #pragma unroll
   for (int m = 0; m < 4; m++) {
@@ -651,9 +653,8 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
 
 template <bool STITCH, bool CLIP, bool MINQ0>
 __device__ __forceinline__ void unit(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
-                                     const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t wlen, int32_t g0) {
-  (void)wlen; (void)g0;
-  process_unit_plain<STITCH, CLIP, MINQ0 && !STITCH>(P, B, L);
+                                     const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t cpo) {
+  process_unit_plain<STITCH, CLIP, MINQ0 && !STITCH>(P, B, L, cpo);
 }
 
 // Advance the CIGAR cursor (c, r, q) = (op index, window position, read index) to the next M
@@ -802,6 +803,14 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     const int32_t r0 = n_r0, r1 = n_r1;
     const int32_t g0 = win.g0, g1 = win.g1;
     const uint32_t wlen = (uint32_t)(g1 - g0);
+    // A short window (a panel target) leaves most columns of the planes unused, and at depth
+    // its few positions are what every lane of an instruction adds to.  It gets ncopy copies
+    // of its nsub columns, lanes spread over them (neighbouring groups of 4 lanes hold
+    // different records over the same positions); the flush adds the copies up.
+    // (only in the launch over deep windows: the first launch stays free of it)
+    const uint32_t nsub = (wlen + 31u) >> 5;
+    const uint32_t ncopy = !DEEP ? 1u : nsub <= 4 ? 8u : nsub <= 8 ? 4u : nsub <= 16 ? 2u : 1u;
+    const uint32_t cpo = DEEP ? (((uint32_t)tid >> 2) & (ncopy - 1u)) * nsub : 0u;
     BP_STAMP(0);
 
     // per-thread record cursor
@@ -1009,7 +1018,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t2 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          unit<STITCH, CLIP, MINQ0>(P, S, L1, wlen, g0);
+          unit<STITCH, CLIP, MINQ0>(P, S, L1, cpo);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -1039,7 +1048,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         for (; it + kD < n_it; it += kD) {
 #pragma unroll
           for (int d = 0; d < kD; d++) {
-            unit<STITCH, CLIP, MINQ0>(P, S, L[d], wlen, g0);
+            unit<STITCH, CLIP, MINQ0>(P, S, L[d], cpo);
             issue_unit<NEED_Q, STITCH>(P, S, t, T, R, L[d]);
             t += kBlock;
           }
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         const uint32_t rem = n_it - it;
 #pragma unroll
         for (int d = 0; d < kD; d++)
-          if ((uint32_t)d < rem) unit<STITCH, CLIP, MINQ0>(P, S, L[d], wlen, g0);
+          if ((uint32_t)d < rem) unit<STITCH, CLIP, MINQ0>(P, S, L[d], cpo);
       }
 #endif
       BP_STAMP(4);
@@ -1064,7 +1073,9 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     const bool upper = (uint32_t)tid >= kHalf;
     const uint32_t p_lo = upper ? (uint32_t)tid - kHalf : kCut + (uint32_t)tid;
     const uint32_t p_hi = upper ? kCut : (uint32_t)kW;
+    const uint32_t p_end = ncopy > 1 ? nsub * 32u : (uint32_t)kW;  // columns past it hold the copies
     for (uint32_t p = p_lo; p < p_hi; p += kHalf) {
+      if (p >= p_end) break;
       uint32_t v[kPlanes];
       uint32_t d = 0;
       uint32_t* const cp = S.cnt + (p & 31u) * kSub + (p >> 5);
@@ -1076,6 +1087,21 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       if (d != 0) {
 #pragma unroll
         for (int c = 0; c < kPlanes; c++) cp[c * kStride] = 0;
+      }
+      for (uint32_t cc = 1; cc < ncopy; cc++) {
+        uint32_t* const cq = cp + cc * nsub;
+        uint32_t dd = 0;
+#pragma unroll
+        for (int c = 0; c < kPlanes; c++) {
+          const uint32_t x = cq[c * kStride];
+          v[c] += x;
+          dd += x;
+        }
+        if (dd != 0) {
+#pragma unroll
+          for (int c = 0; c < kPlanes; c++) cq[c * kStride] = 0;
+        }
+        d += dd;
       }
       if (p >= wlen) continue;
       int64_t R;

@@ -88,14 +88,31 @@ def main():
 
     t0 = time.time()
     threads = min(16, os.cpu_count() or 1)
-    # every rank gets its own contig (seed differs): partition = contig, as in config 3
-    sb = synth.generate([(0, 0, L - 1000, args.coverage)], seed=synth.SEED + rank, threads=threads)
+    from bio_amd import partition
+    # N > 1: ONE contig of N x L positions cut into N position ranges (weak scaling: every
+    # rank owns L positions at the same coverage).  Reads are partitioned, not replicated:
+    # rank g gets the reads that start in its range, so what they contribute behind its end
+    # lands in `tail` extra rows that go to rank g+1 after the kernels (the boundary merge of
+    # BASELINE config 3; the only data-path communication, one small all-gather per step).
+    # (BENCH_EMULATE_RANK=g/N: this single process takes the place of rank g of N, without the
+    # exchange, to check one shard of a large run on a one-GPU box)
+    prank, pworld = rank, world
+    if world == 1 and os.environ.get("BENCH_EMULATE_RANK"):
+        prank, pworld = (int(x) for x in os.environ["BENCH_EMULATE_RANK"].split("/"))
+    tail = 1024 if pworld > 1 else 0
+    total_len = L * pworld
+    start, end, bed_end = partition.boundary_ranges(total_len, pworld, prank, tail)
+    gen_end = end if prank + 1 < pworld else end - 1000
+    sb = synth.generate([(0, start, gen_end, args.coverage)], seed=synth.SEED + prank, threads=threads)
     rb = sb.to_record_batch()
+    if start > 0:  # the generator also starts pairs a little before its region: not ours
+        rb = rb.slice(int(np.searchsorted(rb.pos, start, "left")), rb.n)
     gen_s = time.time() - t0
     B = kept_aligned_bases(rb, opts_kw)
+    own_rows, tail_rows = end - start, bed_end - end
 
-    job = snp.PileupJob(bopts, [L], ["chr1"])
-    job.set_bed({0: [[0, L]]})
+    job = snp.PileupJob(bopts, [total_len], ["chr1"])
+    job.set_bed({0: [[start, bed_end]]})
     job.reserve(rb.n, len(rb.cigar) * 4 + len(rb.seq) + len(rb.qual))
     t0 = time.time()
     job.submit(rb)
@@ -103,8 +120,15 @@ def main():
     submit_s = time.time() - t0
     host_bytes = rb.algorithmic_input_bytes()
 
-    for _ in range(args.warmup):
+    wire = "cuda" if backend == "nccl" else "cpu"
+
+    def step():
         job.compute()
+        if dist is not None:
+            partition.exchange_boundaries(dist, torch, job, own_rows, tail_rows, tail, rank, world, device=wire)
+
+    for _ in range(args.warmup):
+        step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -112,7 +136,7 @@ def main():
     plan_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        job.compute()
+        step()
         t = job.timing()
         kernel_ms.append(t.pileup_ms)
         plan_ms.append(t.plan_ms)
@@ -121,22 +145,33 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        # the only communication of a multi-GPU run: MAX of elapsed, SUM of bases
-        from bio_amd import partition
+        # outside the data path: MAX of elapsed, SUM of bases
         elapsed, total_B = partition.reduce_timing(dist, elapsed, B, device="cuda" if backend == "nccl" else "cpu")
     else:
         total_B = B
 
     # sanity outside the timed region: device depth sum == host-counted aligned bases
     sums = job.column_sums()
-    if sums[0] != B and not os.environ.get("BENCH_TUNING_NO_CHECK"):  # tuning builds may be wrong on purpose
+    if dist is not None:
+        # after the merge: depth over the rows each rank OWNS, summed over ranks, is every
+        # aligned base of every rank (a tail left rank g and arrived at rank g+1)
+        t_sum = 0
+        if tail_rows:
+            tt = torch.zeros(tail_rows * 11, dtype=torch.int32, device="cuda")
+            job.rows_export(own_rows, tail_rows, tt.data_ptr())
+            t_sum = int(tt.view(-1, 11)[:, 0].to(torch.int64).sum().item())
+        both = torch.tensor([sums[0] - t_sum, B], dtype=torch.int64, device=wire)
+        dist.all_reduce(both)
+        if int(both[0]) != int(both[1]):
+            raise SystemExit(f"merged depth over owned rows {int(both[0])} != aligned bases of all ranks {int(both[1])}")
+    elif sums[0] != B and not os.environ.get("BENCH_TUNING_NO_CHECK"):  # tuning builds may be wrong on purpose
         raise SystemExit(f"device depth sum {sums[0]} != host aligned bases {B}")
     algo_bytes = job.algorithmic_bytes()
     n_rows = job.num_rows
     tm = job.timing()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and pworld == 1 and not args.no_cpu_baseline:
         import oracle_lib as O
         sample_bp = int(min(args.cpu_sample_mb * 1e6, L))
         hi = int(np.searchsorted(rb.pos, sample_bp, "left"))
@@ -207,7 +242,10 @@ def main():
                 "workload": f"synthetic {args.coverage:g}x chr1-sized contig ({L} bp) per GPU, 2x150 FR pairs, "
                             "BED = whole contig, basestrand (per-strand) counts, DefaultOpts",
                 "records_per_gpu": rb.n, "aligned_bases_per_gpu": B, "bed_positions_per_gpu": n_rows,
-                "windows": int(tm.n_windows), "partitioning": f"contig per GPU x{world}",
+                "windows": int(tm.n_windows),
+                "partitioning": "one contig, one GPU" if world == 1 else
+                                f"one contig of {total_len} bp cut into {world} position ranges, reads partitioned by "
+                                f"start, {tail}-row boundary merge per step (all-gather of {tail * 44} B per rank)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": "bp::pileup_kernel",

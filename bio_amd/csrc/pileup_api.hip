@@ -30,6 +30,7 @@ namespace bp {
 void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s);
 void launch_pileup(const KernelParams& P, hipStream_t s);
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s);
+void launch_rows_add(uint32_t* rows, const uint32_t* src, int64_t n_u32, hipStream_t s);
 int window_size();
 void launch_list_lengths(const uint32_t* rows, int64_t n_rows, unsigned long long* lens, hipStream_t s);
 void launch_tile_scan(unsigned long long* a, int64_t n, unsigned long long* tile_sum, hipStream_t s);
@@ -826,6 +827,35 @@ int bp_rows_device(bp_handle* h, const uint32_t** dptr) {
   if (!h || !dptr) return fail(h, BP_EINVAL, "bp_rows_device: null argument");
   if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_rows_device: no computed rows");
   *dptr = (const uint32_t*)h->d_rows.p;
+  return BP_OK;
+}
+
+int bp_rows_export(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device) {
+  if (!h || (n > 0 && !dst_device)) return fail(h, BP_EINVAL, "bp_rows_export: null argument");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_rows_export: no computed rows");
+  if (first < 0 || n < 0 || first + n > h->n_rows)
+    return fail(h, BP_EINVAL, "bp_rows_export: rows [%lld, %lld) out of range (%lld rows)", (long long)first,
+                (long long)(first + n), (long long)h->n_rows);
+  if (n == 0) return BP_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(dst_device, (const uint32_t*)h->d_rows.p + first * BP_ROW_U32,
+                            (size_t)n * BP_ROW_U32 * 4, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return BP_OK;
+}
+
+int bp_rows_accumulate(bp_handle* h, int64_t first, int64_t n, const uint32_t* src_device) {
+  if (!h || (n > 0 && !src_device)) return fail(h, BP_EINVAL, "bp_rows_accumulate: null argument");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_rows_accumulate: no computed rows");
+  if (first < 0 || n < 0 || first + n > h->n_rows)
+    return fail(h, BP_EINVAL, "bp_rows_accumulate: rows [%lld, %lld) out of range (%lld rows)", (long long)first,
+                (long long)(first + n), (long long)h->n_rows);
+  if (n == 0) return BP_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  launch_rows_add((uint32_t*)h->d_rows.p + first * BP_ROW_U32, src_device, n * BP_ROW_U32, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->per_read_valid = false;
   return BP_OK;
 }
 

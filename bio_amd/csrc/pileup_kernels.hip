@@ -72,6 +72,9 @@ namespace bp {
 #ifndef BP_DEPTH
 #define BP_DEPTH 3
 #endif
+#ifndef BP_DEPTHS
+#define BP_DEPTHS 1   // ... in the stitched variants (twice the loads per unit)
+#endif
 #ifndef BP_DEPTHQ
 #define BP_DEPTHQ 2
 #endif
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // Every thread runs n_it unit slots (block-uniform).  The steady-state loop has no
         // branch in its body, so the compiler's counted vmcnt waits keep kD units' loads in
         // flight; at 30x a window is 2-3 units per thread and the loop body rarely runs.
-        constexpr int kD = STITCH ? 1 : (NEED_Q ? kDepthQ : kDepth);
+        constexpr int kD = STITCH ? BP_DEPTHS : (NEED_Q ? kDepthQ : kDepth);
         const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
         const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
         UnitLoad<NEED_Q, STITCH> L[kD];
@@ -1328,6 +1331,16 @@ void launch_pileup(const KernelParams& P, hipStream_t s) {
   launch_pileup_variant<false>(P, dim3((P.n_windows + kWinPerBlock - 1) / kWinPerBlock), s);
   // extra slices of deep windows; blocks beyond the item count (read on the device) exit at once
   if (P.extra_items) launch_pileup_variant<true>(P, dim3((unsigned)std::min(P.extra_cap, 2048)), s);
+}
+
+__global__ void rows_add_kernel(uint32_t* rows, const uint32_t* src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    rows[i] += src[i];
+}
+
+void launch_rows_add(uint32_t* rows, const uint32_t* src, int64_t n_u32, hipStream_t s) {
+  const int64_t blocks = (n_u32 + 255) / 256;
+  rows_add_kernel<<<dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s>>>(rows, src, n_u32);
 }
 
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s) {

@@ -104,3 +104,43 @@ def reduce_timing(dist, elapsed_s, units, device="cpu"):
     dist.all_reduce(te, op=dist.ReduceOp.MAX)
     dist.all_reduce(tu, op=dist.ReduceOp.SUM)
     return float(te.item()), int(tu.item())
+
+
+# ---- read-disjoint partition of ONE contig with a boundary merge (SURVEY 8e scheme B) --------
+#
+# Rank g of G owns positions [start_g, end_g) of the contig and is given every read it is
+# told to own, each read to exactly one rank (bench.py: the fragments that start in its range).
+# Its job also covers the `tail` positions behind end_g, where those reads spill over; after
+# the kernels, the tail rows travel to rank g+1 and are added to its first rows.  That is the
+# only data-path communication: one all-gather of tail x 11 uint32 per rank (22-45 KB).
+
+def boundary_ranges(total_len, world_size, rank, tail):
+    """-> (start, end, bed_end): rank's own positions [start, end) and the end of the range its
+    job computes, end + tail clipped to the contig."""
+    start = total_len * rank // world_size
+    end = total_len * (rank + 1) // world_size
+    return start, end, min(end + tail, total_len)
+
+
+def exchange_boundaries(dist, torch, job, own_rows, tail_rows, tail, rank, world_size, device="cuda",
+                        stage="cuda"):
+    """After job.compute(): all-gather the tail rows and add the left neighbour's onto this
+    rank's first rows.  own_rows / tail_rows = this job's row counts inside and behind its own
+    range (tail_rows < tail only for the last rank, which has no right neighbour); `tail` = the
+    fixed row count every rank contributes; own_rows >= tail (a tail reaches one rank far).
+    `device` = where the collective's tensors live ("cuda" for RCCL, "cpu" for a gloo
+    rehearsal); `stage` = where job.rows_export / rows_accumulate read and write ("cuda": the
+    rows stay in HBM; "cpu" only for the host-side stand-in job of the CPU tests)."""
+    if world_size > 1 and own_rows < tail:
+        raise ValueError(f"partition of {own_rows} positions is shorter than the {tail}-row boundary tail")
+    send = torch.zeros(tail * 11, dtype=torch.int32, device=stage)
+    if tail_rows:
+        job.rows_export(own_rows, tail_rows, send.data_ptr())
+    wire = send if device == stage else send.to(device)
+    got = [torch.empty_like(wire) for _ in range(world_size)]
+    dist.all_gather(got, wire)
+    if rank > 0:
+        left = got[rank - 1] if device == stage else got[rank - 1].to(stage)
+        job.rows_accumulate(0, tail, left.data_ptr())
+        if stage == "cuda":
+            torch.cuda.synchronize()

@@ -136,6 +136,14 @@ class PileupJob:
         self._check(self.lib.bp_per_read_features(self.h, lo, hi - lo, feats.ctypes.data_as(C.c_void_p)))
         return off - off[0], feats
 
+    def rows_export(self, first, n, dst_device_ptr):
+        """rows [first, first+n) -> n*11 uint32 at a device address (boundary exchange)"""
+        self._check(self.lib.bp_rows_export(self.h, first, n, dst_device_ptr))
+
+    def rows_accumulate(self, first, n, src_device_ptr):
+        """rows [first, first+n) += n*11 uint32 at a device address (boundary exchange)"""
+        self._check(self.lib.bp_rows_accumulate(self.h, first, n, src_device_ptr))
+
     def column_sums(self):
         s = (C.c_uint64 * _abi.BP_ROW_U32)()
         self._check(self.lib.bp_column_sums(self.h, s))

@@ -148,6 +148,19 @@ int bp_rows(bp_handle* h, int64_t first, int64_t n, int32_t* ref_id, int32_t* po
  * the next bp_compute) for consumers that keep working on the GPU. */
 int bp_rows_device(bp_handle* h, const uint32_t** dptr);
 
+/* Boundary exchange between the devices of a read-disjoint partition (SURVEY 8e scheme B):
+ * when every read is given to exactly one device, the device that owns positions
+ * [start, end) also accumulates, in the rows of [end, end + T), what its reads contribute
+ * past its end; those rows belong to its right neighbour.  bp_rows_export copies the values
+ * of rows [first, first+n) into device memory `dst` (n*BP_ROW_U32 uint32, e.g. a send
+ * buffer); bp_rows_accumulate adds n*BP_ROW_U32 uint32 at device address `src` (what the
+ * left neighbour exported) onto rows [first, first+n).  Both run on the job's stream and
+ * return when done.  Counts are commutative u32 sums (pileup.go:223-231), so the merged
+ * rows equal those of one job over the whole range; the reference has no such step (its
+ * jobs re-read a halo of records instead, pileup.go:896-909). */
+int bp_rows_export(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device);
+int bp_rows_accumulate(bp_handle* h, int64_t first, int64_t n, const uint32_t* src_device);
+
 /* Sum over all rows of each of the BP_ROW_U32 columns (uint64 each), reduced on device.
  * Size-independent parity check: sums[0] = total depth. */
 int bp_column_sums(bp_handle* h, uint64_t sums[BP_ROW_U32]);

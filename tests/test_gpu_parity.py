@@ -281,6 +281,44 @@ def test_logical_partitions_on_one_device(stitch):
         assert_same(got, want, f"{world} partitions stitch={stitch}")
 
 
+def test_boundary_merge_on_device():
+    """bench.py's N > 1 layout on one device: reads partitioned by start over 3 position ranges,
+    each job covering its range plus a tail; bp_rows_export / bp_rows_accumulate move the tails
+    to the right neighbour.  The merged rows are those of one job (and of the oracle)."""
+    import torch
+    from bio_amd import partition as P
+    L, G, tail = 600_000, 3, 1024
+    opts = O.make_opts(min_base_qual=13)
+    sb = synth.generate([(0, 0, L - 1000, 25.0)])
+    rb = sb.to_record_batch()
+    want = device_rows(opts, [L], {0: [[0, L]]}, [rb])
+    assert_same(want, O.pileup(opts, [L], {0: [[0, L]]}, rb), "one job")
+    jobs, spans = [], []
+    for g in range(G):
+        start, end, bed_end = P.boundary_ranges(L, G, g, tail)
+        lo, hi = int(np.searchsorted(rb.pos, start, "left")), int(np.searchsorted(rb.pos, end, "left"))
+        job = snp.PileupJob(opts, [L])
+        job.set_bed({0: [[start, bed_end]]})
+        job.submit(rb.slice(lo, hi))
+        job.finish()
+        jobs.append(job)
+        spans.append((end - start, bed_end - end))
+    # what exchange_boundaries does, with the neighbour in the same process
+    for g in range(G - 1):
+        own, tl = spans[g]
+        buf = torch.zeros(tail * 11, dtype=torch.int32, device="cuda")
+        jobs[g].rows_export(own, tl, buf.data_ptr())
+        jobs[g + 1].rows_accumulate(0, tail, buf.data_ptr())
+    got_pos = np.concatenate([jobs[g].rows(0, spans[g][0])[1] for g in range(G)])
+    got_val = np.concatenate([jobs[g].rows(0, spans[g][0])[2] for g in range(G)])
+    assert (got_pos == want[1]).all() and (got_val == want[2]).all()
+    with pytest.raises(snp.PileupError, match="out of range"):
+        jobs[0].rows_export(spans[0][0], tail + 1, 0)
+    for j in jobs:
+        j.close()
+    sb.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_per_read_lists_vs_oracle(seed):
     """appendBase (pileup.go:235-250): ordered per-read feature lists from the device against

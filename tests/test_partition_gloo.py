@@ -101,6 +101,80 @@ def test_two_ranks_equal_one_job(stitch):
     assert all(len(g[1]) > 0 for g in gathered)
 
 
+# ---- read-disjoint partition of one contig with a boundary merge (bench.py at N > 1) ----------
+class _HostJob:
+    """Stands in for snp.PileupJob: rows in host memory, same export / accumulate calls."""
+
+    def __init__(self, vals):
+        self.vals = np.ascontiguousarray(vals, np.uint32)
+
+    def rows_export(self, first, n, ptr):
+        import ctypes
+        ctypes.memmove(ptr, self.vals[first:first + n].ctypes.data, n * 44)
+
+    def rows_accumulate(self, first, n, ptr):
+        import ctypes
+        add = np.empty((n, 11), np.uint32)
+        ctypes.memmove(add.ctypes.data, ptr, n * 44)
+        self.vals[first:first + n] += add
+
+
+MERGE_LEN, MERGE_TAIL, MERGE_SPAN = 9000, 200, 120
+
+
+def _merge_inputs(seed):
+    rng = random.Random(seed)
+    recs = random_records(rng, 900, ref_len=MERGE_LEN, read_len=40)
+    return R.from_records(recs)
+
+
+def _merge_worker(rank, world, port, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch = _merge_inputs(seed)
+        start, end, bed_end = P.boundary_ranges(MERGE_LEN, world, rank, MERGE_TAIL)
+        # every read goes to exactly one rank: the one that owns its start
+        lo, hi = int(np.searchsorted(batch.pos, start, "left")), int(np.searchsorted(batch.pos, end, "left"))
+        opts = O.make_opts(max_read_len=100, max_read_span=MERGE_SPAN, min_base_qual=20)
+        shard, n = O.region_shard(0, start, bed_end)  # "the job sees exactly what it was handed"
+        _, pos, vals = O.pileup(opts, [MERGE_LEN], {0: [[start, bed_end]]}, batch.slice(lo, hi), shards=shard, n_shards=n)
+        job = _HostJob(vals)
+        P.exchange_boundaries(dist, torch, job, end - start, bed_end - end, MERGE_TAIL, rank, world,
+                              device="cpu", stage="cpu")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (pos[:end - start], job.vals[:end - start]))
+        if rank == 0:
+            q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_boundary_merge_three_ranks_equal_one_job():
+    seed, world = 77, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    batch = _merge_inputs(seed)
+    opts = O.make_opts(max_read_len=100, max_read_span=MERGE_SPAN, min_base_qual=20)
+    wr, wp, wv = O.pileup(opts, [MERGE_LEN], {0: [[0, MERGE_LEN]]}, batch, parallelism=1)
+    gp = np.concatenate([g[0] for g in gathered])
+    gv = np.concatenate([g[1] for g in gathered])
+    assert (gp == wp).all() and (gv == wv).all()
+    # the merge mattered: reads do straddle the cuts
+    cut = MERGE_LEN // world
+    assert ((batch.pos < cut) & (batch.pos + 30 > cut)).any()
+    with pytest.raises(ValueError, match="shorter than"):
+        P.exchange_boundaries(None, torch, None, 10, 200, 200, 0, 2, device="cpu", stage="cpu")
+
+
 def test_plan_partitions_properties():
     rng = random.Random(7)
     for world in (1, 2, 3, 8, 50):

@@ -313,7 +313,9 @@ def test_boundary_merge_on_device():
     got_val = np.concatenate([jobs[g].rows(0, spans[g][0])[2] for g in range(G)])
     assert (got_pos == want[1]).all() and (got_val == want[2]).all()
     with pytest.raises(snp.PileupError, match="out of range"):
-        jobs[0].rows_export(spans[0][0], tail + 1, 0)
+        jobs[0].rows_export(spans[0][0], tail + 1, buf.data_ptr())
+    with pytest.raises(snp.PileupError, match="null argument"):
+        jobs[0].rows_export(spans[0][0], tail, 0)
     for j in jobs:
         j.close()
     sb.close()

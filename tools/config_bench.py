@@ -86,7 +86,42 @@ def main():
     if "c1s" in which:
         ok &= run("30x 20 Mb, stitched min-base-qual 20", [(0, 0, L - 1000, 30.0)], {0: [[0, L]]}, [L],
                   O.make_opts(stitch=1, min_base_qual=20), 2_000_000)
+    if "c5" in which:
+        ok &= run_per_read("c5 60x 20 Mb, per-read lists (-cols dpref,quals)", L, 60.0,
+                           O.make_opts(min_base_qual=13), 200_000)
     sys.exit(0 if ok else 1)
+
+
+def run_per_read(name, L, cov, opts, check_rows):
+    """BASELINE config 5's shape (60x, ordered per-read quals): time of bp_per_read_build after
+    the rows exist; the leading rows' lists are compared with the oracle's entry for entry."""
+    sb = synth.generate([(0, 0, L - 1000, cov)], threads=16)
+    rb = sb.to_record_batch()
+    with snp.PileupJob(opts, [L]) as job:
+        job.set_bed({0: [[0, L]]})
+        job.submit(rb)
+        job.finish()
+        k_ms = job.timing().pileup_ms
+        ts = []
+        for _ in range(3):
+            job.compute()  # invalidates the lists
+            t0 = time.perf_counter()
+            job._check(job.lib.bp_per_read_build(job.h))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        n_feat = int(job.lib.bp_per_read_total(job.h))
+        off, feats = job.per_read(0, check_rows)
+        ab = job.algorithmic_bytes()
+    hi = int(np.searchsorted(rb.pos, check_rows + 600, "left"))
+    _, _, _, woff, wfeat = O.pileup_per_read(opts, [L], {0: [[0, check_rows]]}, rb.slice(0, hi))
+    ok = bool((woff == off).all() and (wfeat == feats).all())
+    t = float(np.median(ts))
+    bytes_ = ab + 6 * n_feat + 32 * L  # + the lists written once and 4 u64 offsets per row
+    print(f"{name}: records {rb.n}  entries {n_feat}  rows kernel {k_ms:.3f} ms  lists {t:.2f} ms "
+          f"(all of bp_per_read_build)  {n_feat / t / 1e6:.1f} Gentry/s  {bytes_ / t / 1e6:.0f} GB/s "
+          f"({bytes_ / t / 1e6 / 8000:.1%} of HBM peak)  parity on {check_rows} rows: {'ok' if ok else 'MISMATCH'}",
+          flush=True)
+    sb.close()
+    return ok
 
 
 if __name__ == "__main__":

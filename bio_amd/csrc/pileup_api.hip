@@ -32,11 +32,10 @@ void launch_pileup(const KernelParams& P, hipStream_t s);
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s);
 void launch_rows_add(uint32_t* rows, const uint32_t* src, int64_t n_u32, hipStream_t s);
 int window_size();
-void launch_list_lengths(const uint32_t* rows, int64_t n_rows, unsigned long long* lens, hipStream_t s);
-void launch_tile_scan(unsigned long long* a, int64_t n, unsigned long long* tile_sum, hipStream_t s);
+void launch_tile_scan(const uint32_t* rows, unsigned long long* a, int64_t n, unsigned long long* tile_sum,
+                      hipStream_t s);
 void launch_tile_add(unsigned long long* a, int64_t n, const unsigned long long* tile_base, hipStream_t s);
-void launch_per_read(const KernelParams& P, const int32_t* iv_ref, int32_t n_iv, int64_t n_rows,
-                     const unsigned long long* off, PerRead* out, int32_t* bad_row, hipStream_t s);
+void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s);
 }  // namespace bp
 
 using namespace bp;
@@ -111,7 +110,7 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_feat, d_items, d_coarse;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_feat, d_items, d_coarse;
   bool per_read_valid = false;
   uint64_t n_feat = 0;
   Staging stage[2];
@@ -625,8 +624,14 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
         rc.pos = b->pos[i];
         rc.flags = b->flags[i];
         rc.mapq = b->mapq[i];
+        const int strand = strand_of(b->ref_id[i], b->mate_ref_id[i], b->flags[i]);
+        const bool keep = ((uint32_t)h->o.flag_exclude & b->flags[i]) == 0 && (int32_t)b->mapq[i] >= h->o.mapq &&
+                          n_cigar != 0 &&
+                          (h->o.strand_req != BP_STRAND_NONE ? strand == h->o.strand_req
+                                                             : (strand != 0 || h->o.ignore_strand));
         rc.aux = (uint8_t)((simple[k] ? AUX_SIMPLE : 0) |
-                           (b->ref_id[i] == b->mate_ref_id[i] ? AUX_MATE_SAME : 0));
+                           (b->ref_id[i] == b->mate_ref_id[i] ? AUX_MATE_SAME : 0) | (keep ? AUX_KEEP : 0) |
+                           (strand << AUX_STRAND_SHIFT));
         rc.n_cigar = (uint16_t)n_cigar;
         rc.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
         rc.l_seq = (uint16_t)std::min<uint32_t>(b->l_seq[i], 0xffffu);
@@ -884,8 +889,7 @@ int bp_per_read_build(bp_handle* h) {
   if (int rc = ensure(h, h->d_pr_off, (size_t)(n + 1) * 8 + 256, 0)) return rc;
   if (int rc = ensure(h, h->d_pr_tiles, (size_t)n_tiles * 8 + 256, 0)) return rc;
   unsigned long long* off = (unsigned long long*)h->d_pr_off.p;
-  launch_list_lengths((const uint32_t*)h->d_rows.p, h->n_rows, off, h->stream);
-  launch_tile_scan(off, n, (unsigned long long*)h->d_pr_tiles.p, h->stream);
+  launch_tile_scan((const uint32_t*)h->d_rows.p, off, n, (unsigned long long*)h->d_pr_tiles.p, h->stream);
   HIP_TRY(h, hipGetLastError());
   std::vector<unsigned long long> tiles((size_t)n_tiles);
   if (n_tiles)
@@ -909,10 +913,24 @@ int bp_per_read_build(bp_handle* h) {
   if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
   const int32_t none = 0x7fffffff;
   HIP_TRY(h, hipMemcpyAsync(h->d_err.p, &none, 4, hipMemcpyHostToDevice, h->stream));
+  // tiles of kPrT positions, cut per BED interval
+  std::vector<int64_t> tile0(n_iv + 1, 0);
+  for (size_t k = 0; k < n_iv; k++)
+    tile0[k + 1] = tile0[k] + ((int64_t)h->iv_end[k] - h->iv_start[k] + kPrT - 1) / kPrT;
+  if (int rc = ensure(h, h->d_pr_tile0, (n_iv + 1) * 8 + 256, 0)) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->d_pr_tile0.p, tile0.data(), (n_iv + 1) * 8, hipMemcpyHostToDevice, h->stream));
   KernelParams P{};
   fill_params(h, P);
-  launch_per_read(P, (const int32_t*)h->d_iv_ref.p, (int32_t)n_iv, h->n_rows, off, (PerRead*)h->d_pr_feat.p,
-                  (int32_t*)h->d_err.p, h->stream);
+  PerReadParams Q{};
+  Q.iv_ref = (const int32_t*)h->d_iv_ref.p;
+  Q.iv_tile0 = (const int64_t*)h->d_pr_tile0.p;
+  Q.off = off;
+  Q.out = (PerRead*)h->d_pr_feat.p;
+  Q.bad_row = (int32_t*)h->d_err.p;
+  Q.n_tiles = tile0[n_iv];
+  Q.n_iv = (int32_t)n_iv;
+  launch_per_read(P, Q, h->stream);
+  // (tile0 outlives the copy: the stream is synchronised below)
   HIP_TRY(h, hipGetLastError());
   int32_t bad = 0;
   HIP_TRY(h, hipMemcpyAsync(&bad, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -973,7 +991,7 @@ void bp_destroy(bp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {

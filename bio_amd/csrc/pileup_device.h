@@ -27,7 +27,11 @@ static_assert(sizeof(ReadCore) == 32, "ReadCore must be 32 bytes");
 
 enum : uint8_t {
   AUX_SIMPLE = 1,     // CIGAR is a single M op
-  AUX_MATE_SAME = 2   // Ref == MateRef (first test of pileup.GetStrand, common.go:95)
+  AUX_MATE_SAME = 2,  // Ref == MateRef (first test of pileup.GetStrand, common.go:95)
+  // what the record-level tests of processShard come to under the job's options, worked out
+  // once by the packer (the per-read gather reads these; the pileup kernel does the tests):
+  AUX_KEEP = 4,       // passes flag-exclude, mapq, empty CIGAR and the strand rule (pileup.go:691, :717-729)
+  AUX_STRAND_SHIFT = 4  // bits 4-5: pileup.GetStrand (0 none, 1 fwd, 2 rev)
 };
 
 // Payload of a record, two 8-byte aligned parts (U = ceil(l_seq/8)):
@@ -114,5 +118,22 @@ struct PerRead {
   uint8_t qual, strand;
 };
 static_assert(sizeof(PerRead) == 6, "PerRead must be 6 bytes");
+
+// The per-read gather: a wave owns a tile of kPrT consecutive positions of one BED interval
+// and keeps in LDS a list of up to kPrPieces (record, M op) pieces that overlap it and the
+// cursors of the tile's lists.
+constexpr int kPrT = 32;          // positions per tile
+constexpr int kPrBlock = 256;     // threads per workgroup, one tile per wave
+constexpr int kPrPieces = 128;    // piece list per wave (16 bytes each); a record has at most kPrT
+constexpr int kPrWaveBytes = kPrPieces * 16 + kPrT * 16;
+struct PerReadParams {
+  const int32_t* iv_ref;          // [n_iv] reference of each flattened BED interval
+  const int64_t* iv_tile0;        // [n_iv + 1] first tile of each interval
+  const unsigned long long* off;  // [4 * n_rows + 1] list offsets (exclusive scan of the counts)
+  PerRead* out;
+  int32_t* bad_row;               // smallest row whose lists disagree with its counts
+  int64_t n_tiles;
+  int32_t n_iv;
+};
 
 }  // namespace bp

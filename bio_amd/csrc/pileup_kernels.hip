@@ -1170,29 +1170,34 @@ __global__ void column_sums_kernel(const uint32_t* rows, int64_t n_rows, unsigne
 // appendBase (pileup.go:235-250): with a per-read column set every passing non-X base also
 // appends {index in read, read length, qual, GetStrand} to PerRead[base] of its position, in
 // read-arrival order.  The list lengths are the counts the pileup kernel already produced
-// (Counts[b][0] + Counts[b][1]), so the lists are laid out by an exclusive scan and filled
-// by a gather: one thread per BED position walks the records that can cover it in index
-// order (= arrival order), which gives the reference's order with no atomics and no sort.
-// This path serves targeted panels and small regions; it is not tuned.
+// (Counts[b][0] + Counts[b][1]), so the lists are laid out by an exclusive scan of the counts
+// and filled by a gather that visits the records in index order (= arrival order): the
+// reference's order with no sort and no contended atomics.
+//
+// The gather is a banded transpose (records x positions -> positions x records) and goes
+// through LDS like one.  A wave owns a tile of kPrT = 32 consecutive BED positions and walks
+// the records that can reach it, 64 at a time:
+//   phase 1  lane = record.  The CIGAR walk leaves one 16-byte piece per M op that overlaps the
+//            tile, in (record, op) order, in a small LDS list (wave prefix sum for the slots).
+//   phase 2  lane = piece.  The 32 bases and quals under the tile are loaded with wide loads and
+//            realigned in registers (tile position k <-> nibble/byte k).  Then, position by
+//            position: a ballot of the lanes whose base is the position's most frequent one
+//            gives every such lane its rank (mbcnt) behind the position's cursor - lanes are
+//            in record order, so ranks are arrival order; the few lanes with another listed base
+//            take a second, per-base ballot.  The lanes of one ballot are consecutive entries
+//            of one list, so every store instruction writes one contiguous run of the output.
 
-// lens[4r + b] = length of list b of row r
-__global__ void list_lengths_kernel(const uint32_t* rows, int64_t n_rows, unsigned long long* lens) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 4 * n_rows) return;
-  const uint32_t* v = rows + (i >> 2) * 11;
-  const int b = (int)(i & 3);
-  lens[i] = (unsigned long long)v[1 + 2 * b] + v[2 + 2 * b];
-}
-
-// In-place exclusive scan of 1024-element tiles; tile totals go to tile_sum.
-__global__ __launch_bounds__(256) void tile_scan_kernel(unsigned long long* a, int64_t n,
+// In-place exclusive scan over tiles of 1024 list lengths, read straight from the rows
+// (lens[4r + b] = Counts[b][0] + Counts[b][1] of row r); tile totals go to tile_sum.
+__global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* rows, unsigned long long* a, int64_t n,
                                                         unsigned long long* tile_sum) {
   __shared__ unsigned long long sh[256];
-  const int64_t base = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 4 lists per row
+  const int64_t base = row * 4;
   unsigned long long v[4], s = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    v[k] = base + k < n ? a[base + k] : 0;
+    v[k] = base + k < n ? (unsigned long long)rows[row * 11 + 1 + 2 * k] + rows[row * 11 + 2 + 2 * k] : 0;
     s += v[k];
   }
   sh[threadIdx.x] = s;
@@ -1217,89 +1222,288 @@ __global__ void tile_add_kernel(unsigned long long* a, int64_t n, const unsigned
   if (i < n) a[i] += tile_base[i >> 10];
 }
 
-__global__ void per_read_kernel(KernelParams P, const int32_t* iv_ref, int32_t n_iv, int64_t n_rows,
-                                const unsigned long long* off, PerRead* out, int32_t* bad_row) {
-  const int64_t R = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (R >= n_rows) return;
-  // row -> (reference, position)
-  int32_t a = 0, b = n_iv;  // last interval with iv_row <= R
-  while (b - a > 1) {
-    const int32_t m = (a + b) >> 1;
-    if (P.iv_row[m] <= R) a = m; else b = m;
-  }
-  const int32_t ref = iv_ref[a];
-  const int32_t p = P.iv_start[a] + (int32_t)(R - P.iv_row[a]);
-  // records of the reference that can cover p: pos in (p - max_span, p]
-  int64_t lo = P.ref_first[ref];
-  const int64_t hi = P.ref_first[ref + 1];
-  {
-    int64_t x = lo, y = hi;
-    const int64_t want = (int64_t)p - P.max_span + 1;
-    while (x < y) {
-      const int64_t m = (x + y) >> 1;
-      if ((int64_t)P.cores[m].pos < want) x = m + 1; else y = m;
-    }
-    lo = x;
-  }
-  uint32_t cnt[4] = {0, 0, 0, 0};
-  for (int64_t i = lo; i < hi; i++) {
-    const ReadCore c = P.cores[i];
-    if (c.pos > p) break;
-    if ((int64_t)c.pos + c.span <= (int64_t)p) continue;
-    // read-level filters (pileup.go:691, :717-729)
-    if (((uint32_t)P.flag_exclude & c.flags) != 0 || (int32_t)c.mapq < P.mapq || c.n_cigar == 0) continue;
-    const int strand = strand_of((c.aux & AUX_MATE_SAME) != 0, c.flags);
-    if (P.strand_req != 0) {
-      if (strand != P.strand_req) continue;
-    } else if (strand == 0 && !P.ignore_strand) {
-      continue;
-    }
-    const int32_t mi = read_index_at(c, P.blob, p);
-    if (mi < 0) continue;
-    const uint8_t* rb = P.blob + (uint64_t)c.blob * 8;
-    const uint32_t cigb = ((c.n_cigar + 1u) & ~1u) * 4;
-    const uint32_t byte = rb[cigb + (mi >> 1)];
-    const uint32_t nib = (mi & 1) ? (byte >> 4) : (byte & 15u);
-    // Seq8ToEnumTable (pileup/common.go:66)
-    const int e = nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : 4;
-    if (e == 4) continue;  // X is counted, never listed (pileup.go:239-240)
-    uint32_t q = rb[8u * c.qdelta + mi];
-    if (P.clip > 0) q = clipped_qual(q, mi, (int32_t)c.l_seq, P.clip);
-    if (q < (uint32_t)P.min_base_qual) continue;
-    const unsigned long long o = off[4 * R + e] + cnt[e];
-    if (o < off[4 * R + e + 1]) {
-      PerRead f;
-      f.dist5p = (uint16_t)mi;
-      f.fraglen = c.l_seq;
-      f.qual = (uint8_t)q;
-      f.strand = (uint8_t)strand;
-      out[o] = f;
-    }
-    cnt[e]++;
-  }
-  // the lists must be exactly as long as the counts said
-  for (int e = 0; e < 4; e++)
-    if (off[4 * R + e] + cnt[e] != off[4 * R + e + 1]) atomicMin(bad_row, (int32_t)(R > 0x7ffffffe ? 0x7ffffffe : R));
+// a[e] without a jump table: e is a lane's own
+__device__ __forceinline__ uint32_t sel4(const uint32_t (&a)[4], uint32_t e) {
+  return (a[0] & (0u - (uint32_t)(e == 0))) | (a[1] & (0u - (uint32_t)(e == 1))) | (a[2] & (0u - (uint32_t)(e == 2))) |
+         (a[3] & (0u - (uint32_t)(e == 3)));
 }
 
-void launch_list_lengths(const uint32_t* rows, int64_t n_rows, unsigned long long* lens, hipStream_t s) {
-  if (n_rows == 0) return;
-  const int64_t n = 4 * n_rows;
-  hipLaunchKernelGGL(list_lengths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, n_rows, lens);
+// bits [lo, hi) of a 32-bit word, lo/hi clamped to [0, 32]
+__device__ __forceinline__ uint32_t bit_range(int32_t lo, int32_t hi) {
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > 32 ? 32 : hi;
+  if (hi <= lo) return 0u;
+  const uint32_t upto_hi = hi >= 32 ? 0xffffffffu : (1u << hi) - 1u;
+  return upto_hi & ~((1u << lo) - 1u);  // lo < hi <= 32: lo <= 31
 }
-void launch_tile_scan(unsigned long long* a, int64_t n, unsigned long long* tile_sum, hipStream_t s) {
+
+// One entry of a list.  The lanes of a store are consecutive entries of one list (ranks of
+// one ballot), so a wave instruction writes one contiguous run of the output.
+__device__ __forceinline__ void pr_put(uint8_t* gout, uint32_t n_tile, uint32_t slot, uint32_t w01, uint32_t w2) {
+  if (slot >= n_tile) return;  // a list longer than its count: reported at the end of the tile
+  uint16_t* d = (uint16_t*)(gout + 6ull * slot);
+  d[0] = (uint16_t)w01; d[1] = (uint16_t)(w01 >> 16); d[2] = (uint16_t)w2;
+}
+
+template <bool CLIP>
+__global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerReadParams Q) {
+  extern __shared__ __align__(16) uint8_t pr_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * (kPrBlock / 64) + wave;
+  if (t >= Q.n_tiles) return;  // wave-uniform; the kernel has no workgroup barrier
+  uint8_t* const wl = pr_lds + (size_t)wave * kPrWaveBytes;
+  uint4* const pieces = (uint4*)wl;                               // [kPrPieces]
+  uint32_t* const cur = (uint32_t*)(wl + kPrPieces * 16);         // [kPrT][4] next free entry of every list
+  // tile -> interval, positions, rows
+  int32_t a = 0, b = Q.n_iv;  // last interval with iv_tile0 <= t
+  while (b - a > 1) {
+    const int32_t m = (a + b) >> 1;
+    if (Q.iv_tile0[m] <= t) a = m; else b = m;
+  }
+  const int32_t ref = Q.iv_ref[a];
+  const int64_t chunk = t - Q.iv_tile0[a];
+  const int32_t p0 = P.iv_start[a] + (int32_t)(chunk * kPrT);
+  const int32_t iv_end = P.iv_end[a];
+  const int32_t pend = iv_end - p0 < kPrT ? iv_end : p0 + kPrT;  // the tile is [p0, pend)
+  const int32_t n_pos = pend - p0;
+  const int64_t R0 = P.iv_row[a] + chunk * kPrT;
+  const unsigned long long off0 = Q.off[4 * R0], off1 = Q.off[4 * (R0 + n_pos)];
+  const uint32_t n_tile = (uint32_t)(off1 - off0 > 0xffffffffull ? 0xffffffffull : off1 - off0);
+  // lane k < 32 holds position k's state: its four lists inside the tile's stretch of the
+  // output, which of them is the longest ("major": it gets the cheap path), the major list's
+  // cursor (v_cur) and base code (v_maj).  The other cursors live in LDS.
+  const int pl = lane & (kPrT - 1);
+  const bool active = lane < kPrT && pl < n_pos;
+  uint32_t lbase[4] = {0, 0, 0, 0}, llen[4] = {0, 0, 0, 0};
+  if (active) {
+    unsigned long long o[5];
+#pragma unroll
+    for (int e = 0; e < 5; e++) o[e] = Q.off[4 * (R0 + pl) + e];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      lbase[e] = (uint32_t)(o[e] - off0);
+      llen[e] = (uint32_t)(o[e + 1] - o[e]);
+    }
+  }
+  uint32_t maj = 0;
+#pragma unroll
+  for (uint32_t e = 1; e < 4; e++)
+    if (llen[e] > sel4(llen, maj)) maj = e;
+  uint32_t v_cur = sel4(lbase, maj);
+  const uint32_t v_maj = 1u << maj;  // Seq8 code of the major base (fasta.go:50-62)
+  if (lane < kPrT) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) cur[pl * 4 + e] = lbase[e];
+  }
+  uint8_t* const gout = (uint8_t*)Q.out + off0 * 6;  // the tile's lists are one stretch of the output
+
+  // records of the reference that can cover the tile: pos in (p0 - max_span, pend)
+  const int64_t hi = P.ref_first[ref + 1];
+  int64_t want = (int64_t)p0 - P.max_span + 1;
+  if (want < 0) want = 0;
+  const int64_t lo = first_at_or_after(P, P.ref_first[ref], hi, want);
+  const uint4* cores4 = (const uint4*)P.cores;
+  const uint32_t minq = (uint32_t)P.min_base_qual;
+
+  for (int64_t i = lo; i < hi;) {
+    // ---- phase 1: lane = record i + lane -> pieces
+    const bool have = i + lane < hi;
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+    if (have) {
+      c0 = cores4[2 * (i + lane)];
+      c1 = cores4[2 * (i + lane) + 1];
+    }
+    const int32_t pos = (int32_t)c0.x;
+    const uint32_t aux = c0.y >> 24, n_cigar = c0.z & 0xffffu, span = c0.z >> 16, l_seq = c0.w & 0xffffu,
+                   qdelta = c0.w >> 16;
+    // records are sorted: once one starts behind the tile, so does every later one
+    const bool last_batch = __builtin_amdgcn_ballot_w64(!have || pos >= pend) != 0;
+    // record-level tests (pileup.go:691, :717-729) were folded into AUX_KEEP by the packer
+    const bool rel = have && (aux & AUX_KEEP) && pos < pend && (int64_t)pos + span > (int64_t)p0;
+    const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)c1.x * 8);
+    uint32_t n_mine = 0;
+    if (rel) {
+      if (aux & AUX_SIMPLE) {
+        n_mine = 1;
+      } else {
+        int32_t r = pos;
+        for (uint32_t k = 0; k < n_cigar && r < pend; k++) {
+          const uint32_t w = k == 0 ? c1.y : k == 1 ? c1.z : k == 2 ? c1.w : cg[k];
+          const uint32_t op = w & 15u;
+          const int32_t len = (int32_t)(w >> 4);
+          if (op == 0) {
+            if (len > 0 && r + len > p0) n_mine++;   // r < pend holds
+            r += len;
+          } else if (op == 2 || op == 3) {
+            r += len;
+          } else if (op != 1 && op != 4 && op != 5) {
+            break;
+          }
+        }
+      }
+    }
+    const uint32_t incl = wave_inclusive_scan(n_mine);
+    // records whose pieces fit the list this round (a record has at most kPrT pieces)
+    const unsigned long long fit = __builtin_amdgcn_ballot_w64(incl <= (uint32_t)kPrPieces);
+    const int n_take = fit == ~0ull ? 64 : __builtin_ctzll(~fit);
+    const uint32_t n_pieces = (uint32_t)__builtin_amdgcn_readlane((int)incl, n_take - 1);
+    if (rel && lane < n_take && n_mine) {
+      uint32_t slot = incl - n_mine;
+      const uint32_t dz = qdelta | (((n_cigar + 1u) >> 1) << 16);
+      const uint32_t dw = l_seq | (((aux >> AUX_STRAND_SHIFT) & 3u) << 16);
+      if (aux & AUX_SIMPLE) {
+        const int32_t pa = pos > p0 ? pos - p0 : 0;
+        const int32_t pb = ((int64_t)pos + span < (int64_t)pend ? pos + (int32_t)span : pend) - p0;
+        pieces[slot] = make_uint4(c1.x, ((uint32_t)(p0 - pos) & 0xfffffu) | ((uint32_t)pa << 20) | ((uint32_t)pb << 26), dz, dw);
+      } else {
+        int32_t r = pos, qi = 0;
+        for (uint32_t k = 0; k < n_cigar && r < pend; k++) {
+          const uint32_t w = k == 0 ? c1.y : k == 1 ? c1.z : k == 2 ? c1.w : cg[k];
+          const uint32_t op = w & 15u;
+          const int32_t len = (int32_t)(w >> 4);
+          if (op == 0) {
+            if (len > 0 && r + len > p0) {
+              const int32_t pa = r > p0 ? r - p0 : 0;
+              const int32_t pb = (r + len < pend ? r + len : pend) - p0;
+              pieces[slot++] = make_uint4(c1.x, ((uint32_t)(qi + p0 - r) & 0xfffffu) | ((uint32_t)pa << 20) | ((uint32_t)pb << 26), dz, dw);
+            }
+            r += len; qi += len;
+          } else if (op == 1 || op == 4) {
+            qi += len;
+          } else if (op == 2 || op == 3) {
+            r += len;
+          } else if (op != 5) {
+            break;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 2: lane = piece
+    for (uint32_t pc = 0; pc < n_pieces; pc += 64) {
+      const bool mine = pc + lane < n_pieces;
+      uint4 d = make_uint4(0, 0, 0, 0);
+      if (mine) d = pieces[pc + lane];
+      const int32_t x0 = ((int32_t)(d.y << 12)) >> 12;   // read index under tile position 0 (may be < 0)
+      const int32_t pa = (int32_t)((d.y >> 20) & 63u), pb = (int32_t)(d.y >> 26);  // valid tile positions [pa, pb)
+      const uint32_t pl_seq = d.w & 0xffffu;
+      const uint32_t w2hi = ((d.w >> 16) & 3u) << 8;
+      const uint8_t* rb = P.blob + (uint64_t)d.x * 8;
+      // 32 bases under the tile: nibbles x0 .. x0+31 of the packed bases
+      uint32_t B[4];
+      {
+        const uint32_t* bp = (const uint32_t*)(rb + (size_t)(d.z >> 16) * 8) + (x0 >> 3);
+        uint32_t r[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) r[j] = bp[j];
+        const uint32_t sh = ((uint32_t)x0 & 7u) * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          B[j] = __builtin_amdgcn_alignbit(r[j + 1], r[j], sh);
+          B[j] &= bit_range(4 * (pa - 8 * j), 4 * (pb - 8 * j));  // positions outside the piece read as 0
+        }
+      }
+      // and the 32 quals: bytes x0 .. x0+31
+      uint32_t Qv[8];
+      {
+        const uint32_t* qp = (const uint32_t*)(rb + 8ull * (d.z & 0xffffu)) + (x0 >> 2);
+        uint32_t r[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) r[j] = qp[j];
+        const uint32_t sh = ((uint32_t)x0 & 3u) * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) Qv[j] = __builtin_amdgcn_alignbit(r[j + 1], r[j], sh);
+      }
+      uint32_t clipped = 0;  // tile positions whose qual clipQuals sets to 2 (pileup_support.go:47-69)
+      if (CLIP) {
+        if (2 * P.clip >= (int32_t)pl_seq) clipped = 0xffffffffu;
+        else clipped = bit_range(0, P.clip - x0) | bit_range((int32_t)pl_seq - P.clip - x0, 32);
+      }
+#pragma unroll 1
+      for (int j = 0; j < kPrT / 8; j++) {
+        const uint32_t Bj = B[0], Q0 = Qv[0], Q1 = Qv[1];
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+          const int k = 8 * j + kk;
+          const uint32_t nib = (Bj >> (4 * kk)) & 15u;
+          uint32_t q = ((kk < 4 ? Q0 : Q1) >> (8 * (kk & 3))) & 255u;
+          if (CLIP) q = (clipped >> k) & 1u ? 2u : q;
+          const bool qok = q >= minq;
+          const uint32_t s_maj = (uint32_t)__builtin_amdgcn_readlane((int)v_maj, k);
+          const bool is_major = nib == s_maj && qok;
+          const unsigned long long M = __builtin_amdgcn_ballot_w64(is_major);
+          const unsigned long long Pm = __builtin_amdgcn_ballot_w64(nib != 0 && qok);
+          const uint32_t w01 = (uint32_t)(x0 + k) | (pl_seq << 16);
+          const uint32_t w2 = q | w2hi;
+          if (M) {
+            const uint32_t s_cur = (uint32_t)__builtin_amdgcn_readlane((int)v_cur, k);
+            if (is_major) {
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+              pr_put(gout, n_tile, s_cur + rank, w01, w2);
+            }
+            v_cur = lane == k ? s_cur + (uint32_t)__builtin_popcountll(M) : v_cur;
+          }
+          if (Pm != M) {
+            // other listed bases (Seq8ToEnumTable, pileup/common.go:66: 1,2,4,8 -> A,C,G,T; anything
+            // else is X: counted, never listed, pileup.go:239-240)
+            const bool minor = nib != 0 && qok && !is_major && (nib & (nib - 1)) == 0;
+            const uint32_t e = (nib >> 1) - (nib >> 3);
+#pragma unroll
+            for (uint32_t e2 = 0; e2 < 4; e2++) {
+              const unsigned long long Me = __builtin_amdgcn_ballot_w64(minor && e == e2);
+              if (Me) {
+                const uint32_t c = cur[k * 4 + e2];
+                if (minor && e == e2) {
+                  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Me, 0u));
+                  pr_put(gout, n_tile, c + rank, w01, w2);
+                  if (rank == 0) cur[k * 4 + e2] = c + (uint32_t)__builtin_popcountll(Me);
+                }
+              }
+            }
+          }
+        }
+        // next 8 positions
+        B[0] = B[1]; B[1] = B[2]; B[2] = B[3];
+#pragma unroll
+        for (int x = 0; x < 6; x++) Qv[x] = Qv[x + 2];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (last_batch && n_take == 64) break;
+    i += n_take;
+  }
+  // the lists must be exactly as long as the counts said
+  if (active) {
+    bool complete = true;
+#pragma unroll
+    for (uint32_t e = 0; e < 4; e++) {
+      const uint32_t endc = e == maj ? v_cur : cur[pl * 4 + e];
+      complete = complete && endc == lbase[e] + llen[e];
+    }
+    if (!complete) {
+      const int64_t R = R0 + pl;
+      atomicMin(Q.bad_row, (int32_t)(R > 0x7ffffffe ? 0x7ffffffe : R));
+    }
+  }
+}
+
+void launch_tile_scan(const uint32_t* rows, unsigned long long* a, int64_t n, unsigned long long* tile_sum,
+                      hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, a, n, tile_sum);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, rows, a, n, tile_sum);
 }
 void launch_tile_add(unsigned long long* a, int64_t n, const unsigned long long* tile_base, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(tile_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, tile_base);
 }
-void launch_per_read(const KernelParams& P, const int32_t* iv_ref, int32_t n_iv, int64_t n_rows,
-                     const unsigned long long* off, PerRead* out, int32_t* bad_row, hipStream_t s) {
-  if (n_rows == 0) return;
-  hipLaunchKernelGGL(per_read_kernel, dim3((unsigned)((n_rows + 127) / 128)), dim3(128), 0, s, P, iv_ref, n_iv,
-                     n_rows, off, out, bad_row);
+int per_read_tile_positions() { return kPrT; }
+void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s) {
+  if (Q.n_tiles == 0) return;
+  const size_t lds = (size_t)kPrWaveBytes * (kPrBlock / 64);
+  const dim3 grid((unsigned)((Q.n_tiles + kPrBlock / 64 - 1) / (kPrBlock / 64))), block(kPrBlock);
+  if (P.clip > 0) hipLaunchKernelGGL((per_read_kernel<true>), grid, block, lds, s, P, Q);
+  else hipLaunchKernelGGL((per_read_kernel<false>), grid, block, lds, s, P, Q);
 }
 
 // ---- launch wrappers (called from pileup_api.hip)

@@ -361,3 +361,63 @@ def test_per_read_lists_vs_oracle(seed):
         job.finish()
         with pytest.raises(snp.PileupError, match="stitched per-read features not yet supported"):
             job.per_read()
+
+
+@pytest.mark.parametrize("case", ["deep_spot", "many_ops", "dense"])
+def test_per_read_lists_deep_and_fragmented(case):
+    """The per-read gather beyond its common case: a tile whose lists exceed the LDS staging
+    area (entries stored directly), more (record, M op) pieces than one round's list holds,
+    and uniformly deep tiles that fill the staging area; each against the oracle."""
+    rng = random.Random({"deep_spot": 71, "many_ops": 72, "dense": 73}[case])
+    L = 60_000 if case == "deep_spot" else 3_000
+    recs = []
+
+    def rec(k, pos, cg, lq):
+        seq = "".join(rng.choice("ACGTACGTACGTACGTN") for _ in range(lq))
+        return dict(name="r%d" % k, ref_id=0, pos=pos, mapq=60, flags=0x1 | 0x2 | 0x20 | 0x40, cigar=cg, seq=seq,
+                    qual=[rng.choice([2, 12, 23, 37, 41]) for _ in range(lq)], mate_ref_id=0, mate_pos=pos + 100)
+    if case == "deep_spot":
+        # a thin background and 900 reads piled on ~150 positions: the staging area is sized
+        # for the average tile, so the spot's tiles take the direct path
+        for k in range(300):
+            recs.append(rec(k, rng.randint(0, L - 200), [("M", 80)], 80))
+        for k in range(900):
+            a = rng.randint(10, 60)
+            recs.append(rec(1000 + k, 30_000 + rng.randint(0, 60), [("S", 3), ("M", a), ("D", 2), ("M", 70 - a)], 73))
+    elif case == "many_ops":
+        # 1M1D / 2M1I ladders: up to 30 M ops under one 32-position tile, 200 such records on
+        # the same stretch -> several rounds of the piece list per batch of 64 records
+        for k in range(260):
+            cg, lq = [], 0
+            for _ in range(rng.randint(20, 40)):
+                m = rng.randint(1, 3)
+                cg.append(("M", m))
+                lq += m
+                if rng.random() < 0.5:
+                    cg.append(("D", rng.randint(1, 2)))
+                else:
+                    i = rng.randint(1, 2)
+                    cg.append(("I", i))
+                    lq += i
+            cg.append(("M", 5))
+            lq += 5
+            recs.append(rec(k, 500 + rng.randint(0, 120), cg, lq))
+    else:
+        for k in range(4000):
+            a = rng.randint(5, 90)
+            cg = [("M", 100)] if k % 3 else [("M", a), ("I", 2), ("M", 98 - a)]
+            recs.append(rec(k, rng.randint(0, L - 150), cg, 100))
+    recs.sort(key=lambda x: x["pos"])
+    batch = R.from_records(recs)
+    bed = {0: [[0, L]]} if case != "many_ops" else {0: [[400, 431], [433, 700], [701, 702], [800, 900]]}
+    opts = O.make_opts(max_read_len=200, max_read_span=300, min_base_qual=13, clip=2 if case == "dense" else 0)
+    wr, wp, wv, woff, wf = O.pileup_per_read(opts, [L], bed, batch)
+    with snp.PileupJob(opts, [L]) as job:
+        job.set_bed(bed)
+        job.submit(batch)
+        job.finish()
+        assert_same(job.rows(), (wr, wp, wv), "rows")
+        off, feats = job.per_read()
+        assert (off == woff).all()
+        assert feats.tobytes() == wf.tobytes()
+        assert len(feats) > 5_000

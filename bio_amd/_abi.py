@@ -57,6 +57,8 @@ class bp_timing(C.Structure):
         ("total_ms", C.c_float),
         ("n_windows", C.c_int64),
         ("n_items", C.c_int64),
+        ("per_read_ms", C.c_float),
+        ("per_read_scan_ms", C.c_float),
     ]
 
 

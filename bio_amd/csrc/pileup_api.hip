@@ -32,9 +32,7 @@ void launch_pileup(const KernelParams& P, hipStream_t s);
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s);
 void launch_rows_add(uint32_t* rows, const uint32_t* src, int64_t n_u32, hipStream_t s);
 int window_size();
-void launch_tile_scan(const uint32_t* rows, unsigned long long* a, int64_t n, unsigned long long* tile_sum,
-                      hipStream_t s);
-void launch_tile_add(unsigned long long* a, int64_t n, const unsigned long long* tile_base, hipStream_t s);
+void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned long long* tile_sum, hipStream_t s);
 void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s);
 }  // namespace bp
 
@@ -110,9 +108,10 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_feat, d_items, d_coarse;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_tile_lo, d_pr_feat, d_items, d_coarse;
   bool per_read_valid = false;
   uint64_t n_feat = 0;
+  std::vector<unsigned long long> pr_tile_base;  // per 1024 lists: entries before them
   Staging stage[2];
   int cur_stage = 0;
   bp_timing timing{};
@@ -886,27 +885,29 @@ int bp_per_read_build(bp_handle* h) {
   HIP_TRY(h, hipSetDevice(h->device));
   const int64_t n = 4 * h->n_rows;
   const int64_t n_tiles = (n + 1023) / 1024;
-  if (int rc = ensure(h, h->d_pr_off, (size_t)(n + 1) * 8 + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_pr_off, (size_t)n * 4 + 256, 0)) return rc;
   if (int rc = ensure(h, h->d_pr_tiles, (size_t)n_tiles * 8 + 256, 0)) return rc;
-  unsigned long long* off = (unsigned long long*)h->d_pr_off.p;
-  launch_tile_scan((const uint32_t*)h->d_rows.p, off, n, (unsigned long long*)h->d_pr_tiles.p, h->stream);
+  uint32_t* off32 = (uint32_t*)h->d_pr_off.p;
+  HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+  launch_tile_scan((const uint32_t*)h->d_rows.p, off32, n, (unsigned long long*)h->d_pr_tiles.p, h->stream);
   HIP_TRY(h, hipGetLastError());
-  std::vector<unsigned long long> tiles((size_t)n_tiles);
+  std::vector<unsigned long long>& tiles = h->pr_tile_base;  // kept: bp_per_read_offsets adds them on the host
+  tiles.assign((size_t)n_tiles, 0);
   if (n_tiles)
     HIP_TRY(h, hipMemcpyAsync(tiles.data(), h->d_pr_tiles.p, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   unsigned long long run = 0;
   for (auto& t : tiles) {
     const unsigned long long v = t;
+    if (v > 0xffffffffull) return fail(h, BP_EINVAL, "bp_per_read_build: more than 2^32 list entries on 256 positions");
     t = run;
     run += v;
   }
   h->n_feat = run;
   if (n_tiles)
     HIP_TRY(h, hipMemcpyAsync(h->d_pr_tiles.p, tiles.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, h->stream));
-  launch_tile_add(off, n, (const unsigned long long*)h->d_pr_tiles.p, h->stream);
-  HIP_TRY(h, hipMemcpyAsync(off + n, &run, 8, hipMemcpyHostToDevice, h->stream));
-  if (int rc = ensure(h, h->d_pr_feat, (size_t)run * sizeof(PerRead) + 256, 0)) return rc;
+  // + 64 entries of slack behind the last list (see the per-chunk cursor check in per_read_kernel)
+  if (int rc = ensure(h, h->d_pr_feat, ((size_t)run + 64) * sizeof(PerRead) + 256, 0)) return rc;
   const size_t n_iv = h->iv_ref.size();
   if (int rc = ensure(h, h->d_iv_ref, n_iv * 4 + 256, 0)) return rc;
   if (n_iv) HIP_TRY(h, hipMemcpyAsync(h->d_iv_ref.p, h->iv_ref.data(), n_iv * 4, hipMemcpyHostToDevice, h->stream));
@@ -924,17 +925,26 @@ int bp_per_read_build(bp_handle* h) {
   PerReadParams Q{};
   Q.iv_ref = (const int32_t*)h->d_iv_ref.p;
   Q.iv_tile0 = (const int64_t*)h->d_pr_tile0.p;
-  Q.off = off;
+  Q.off32 = off32;
+  Q.tile_base = (const unsigned long long*)h->d_pr_tiles.p;
+  Q.total = run;
+  Q.n_lists = n;
   Q.out = (PerRead*)h->d_pr_feat.p;
   Q.bad_row = (int32_t*)h->d_err.p;
   Q.n_tiles = tile0[n_iv];
+  if (int rc = ensure(h, h->d_pr_tile_lo, (size_t)Q.n_tiles * 4 + 256, 0)) return rc;
+  Q.tile_lo = (const int32_t*)h->d_pr_tile_lo.p;
   Q.n_iv = (int32_t)n_iv;
+  HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
   launch_per_read(P, Q, h->stream);
+  HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
   // (tile0 outlives the copy: the stream is synchronised below)
   HIP_TRY(h, hipGetLastError());
   int32_t bad = 0;
   HIP_TRY(h, hipMemcpyAsync(&bad, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  (void)hipEventElapsedTime(&h->timing.per_read_scan_ms, h->ev[0], h->ev[1]);
+  (void)hipEventElapsedTime(&h->timing.per_read_ms, h->ev[1], h->ev[2]);
   if (bad != none)
     return fail(h, BP_EDEVICE, "bp_per_read_build: list lengths of row %d disagree with its counts", bad);
   h->per_read_valid = true;
@@ -950,8 +960,16 @@ int bp_per_read_offsets(bp_handle* h, int64_t first_row, int64_t n_rows, uint64_
     return fail(h, BP_EINVAL, "bp_per_read_offsets: rows [%lld,%lld) of %lld", (long long)first_row,
                 (long long)(first_row + n_rows), (long long)h->n_rows);
   HIP_TRY(h, hipSetDevice(h->device));
-  HIP_TRY(h, hipMemcpy(off, (const uint64_t*)h->d_pr_off.p + 4 * first_row, (size_t)(4 * n_rows + 1) * 8,
-                       hipMemcpyDeviceToHost));
+  const int64_t i0 = 4 * first_row, m = 4 * n_rows;
+  std::vector<uint32_t> rel((size_t)m);
+  if (m) HIP_TRY(h, hipMemcpy(rel.data(), (const uint32_t*)h->d_pr_off.p + i0, (size_t)m * 4, hipMemcpyDeviceToHost));
+  for (int64_t k = 0; k < m; k++) off[k] = h->pr_tile_base[(size_t)((i0 + k) >> 10)] + rel[(size_t)k];
+  off[m] = i0 + m >= 4 * h->n_rows ? h->n_feat : h->pr_tile_base[(size_t)((i0 + m) >> 10)] + 0;
+  if (i0 + m < 4 * h->n_rows) {  // the first list behind the range
+    uint32_t nxt = 0;
+    HIP_TRY(h, hipMemcpy(&nxt, (const uint32_t*)h->d_pr_off.p + i0 + m, 4, hipMemcpyDeviceToHost));
+    off[m] += nxt;
+  }
   return BP_OK;
 }
 
@@ -991,7 +1009,7 @@ void bp_destroy(bp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_tile_lo, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {

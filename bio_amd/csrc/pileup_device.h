@@ -125,11 +125,16 @@ static_assert(sizeof(PerRead) == 6, "PerRead must be 6 bytes");
 constexpr int kPrT = 32;          // positions per tile
 constexpr int kPrBlock = 256;     // threads per workgroup, one tile per wave
 constexpr int kPrPieces = 128;    // piece list per wave (16 bytes each); a record has at most kPrT
-constexpr int kPrWaveBytes = kPrPieces * 16 + kPrT * 16;
+constexpr int kPrWaveBytes = kPrPieces * 16 + kPrT * 16 + kPrT * 4;
 struct PerReadParams {
   const int32_t* iv_ref;          // [n_iv] reference of each flattened BED interval
   const int64_t* iv_tile0;        // [n_iv + 1] first tile of each interval
-  const unsigned long long* off;  // [4 * n_rows + 1] list offsets (exclusive scan of the counts)
+  // list offsets = exclusive scan of the counts: list i starts at tile_base[i >> 10] + off32[i]
+  const uint32_t* off32;          // [n_lists = 4 * n_rows]
+  const unsigned long long* tile_base;  // [ceil(n_lists / 1024)]
+  unsigned long long total;       // entries in all lists
+  int64_t n_lists;
+  const int32_t* tile_lo;         // [n_tiles] first record that can reach the tile (per_read_plan_kernel)
   PerRead* out;
   int32_t* bad_row;               // smallest row whose lists disagree with its counts
   int64_t n_tiles;

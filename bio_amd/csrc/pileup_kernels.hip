@@ -1187,9 +1187,11 @@ __global__ void column_sums_kernel(const uint32_t* rows, int64_t n_rows, unsigne
 //            take a second, per-base ballot.  The lanes of one ballot are consecutive entries
 //            of one list, so every store instruction writes one contiguous run of the output.
 
-// In-place exclusive scan over tiles of 1024 list lengths, read straight from the rows
-// (lens[4r + b] = Counts[b][0] + Counts[b][1] of row r); tile totals go to tile_sum.
-__global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* rows, unsigned long long* a, int64_t n,
+// List lengths (lens[4r + b] = Counts[b][0] + Counts[b][1] of row r, read straight from the
+// rows) scanned in tiles of 1024 lists: off32 gets the exclusive sum inside the tile, tile_sum
+// the tile's total.  The host scans the totals; a list's offset is tile_base[i >> 10] + off32[i]
+// (pr_off), so there is no second pass over the offsets.
+__global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* rows, uint32_t* off32, int64_t n,
                                                         unsigned long long* tile_sum) {
   __shared__ unsigned long long sh[256];
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 4 lists per row
@@ -1209,17 +1211,20 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* rows, un
     __syncthreads();
   }
   unsigned long long run = sh[threadIdx.x] - s;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (base + k < n) a[base + k] = run;
-    run += v[k];
+  if (base < n) {  // n is a multiple of 4; a tile's total is checked against 2^32 on the host
+    uint4 o;
+    o.x = (uint32_t)run; run += v[0];
+    o.y = (uint32_t)run; run += v[1];
+    o.z = (uint32_t)run; run += v[2];
+    o.w = (uint32_t)run;
+    *(uint4*)(off32 + base) = o;
   }
   if (threadIdx.x == 255) tile_sum[blockIdx.x] = sh[255];
 }
 
-__global__ void tile_add_kernel(unsigned long long* a, int64_t n, const unsigned long long* tile_base) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] += tile_base[i >> 10];
+// offset of list i (i = 4 x row + base; i = n_lists gives the total)
+__device__ __forceinline__ unsigned long long pr_off(const PerReadParams& Q, int64_t i) {
+  return i >= Q.n_lists ? Q.total : Q.tile_base[i >> 10] + Q.off32[i];
 }
 
 // a[e] without a jump table: e is a lane's own
@@ -1238,47 +1243,76 @@ __device__ __forceinline__ uint32_t bit_range(int32_t lo, int32_t hi) {
 }
 
 // One entry of a list.  The lanes of a store are consecutive entries of one list (ranks of
-// one ballot), so a wave instruction writes one contiguous run of the output.
-__device__ __forceinline__ void pr_put(uint8_t* gout, uint32_t n_tile, uint32_t slot, uint32_t w01, uint32_t w2) {
-  if (slot >= n_tile) return;  // a list longer than its count: reported at the end of the tile
-  uint16_t* d = (uint16_t*)(gout + 6ull * slot);
+// one ballot), so a wave instruction writes one contiguous run of the output.  6 x slot is a
+// 32-bit byte offset from a scalar base (a tile's lists stay far below 4 GiB).
+__device__ __forceinline__ void pr_put(uint8_t* gout, uint32_t slot, uint32_t w01, uint32_t w2) {
+  uint16_t* d = (uint16_t*)(gout + ((slot << 2) + (slot << 1)));
   d[0] = (uint16_t)w01; d[1] = (uint16_t)(w01 >> 16); d[2] = (uint16_t)w2;
+}
+
+// tile -> its BED interval and its index inside it
+__device__ __forceinline__ int32_t pr_tile_interval(const PerReadParams& Q, int64_t t, int64_t& chunk) {
+  int32_t a = 0, b = Q.n_iv;  // last interval with iv_tile0 <= t
+  while (b - a > 1) {
+    const int32_t m = (a + b) >> 1;
+    if (Q.iv_tile0[m] <= t) a = m; else b = m;
+  }
+  chunk = t - Q.iv_tile0[a];
+  return a;
+}
+
+// Per tile: the first record that can reach it (pos > first position - max_span).  A kernel of
+// its own, thread = tile: the searches are chains of dependent loads, which thousands of
+// independent threads hide and one wave per tile does not.
+__global__ void per_read_plan_kernel(KernelParams P, PerReadParams Q, int32_t* tile_lo) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Q.n_tiles) return;
+  int64_t chunk;
+  const int32_t a = pr_tile_interval(Q, t, chunk);
+  const int32_t ref = Q.iv_ref[a];
+  int64_t want = (int64_t)P.iv_start[a] + chunk * kPrT - P.max_span + 1;
+  if (want < 0) want = 0;
+  tile_lo[t] = (int32_t)first_at_or_after(P, P.ref_first[ref], P.ref_first[ref + 1], want);
 }
 
 template <bool CLIP>
 __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerReadParams Q) {
   extern __shared__ __align__(16) uint8_t pr_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t t = (int64_t)blockIdx.x * (kPrBlock / 64) + wave;
+  // consecutive workgroups go to different XCDs, each with its own L2: give every XCD a
+  // contiguous run of tiles, so that the records neighbouring tiles share come from one L2
+  const uint32_t per_xcd = gridDim.x >> 3;  // the launcher rounds the grid up to a multiple of 8
+  const int64_t t = ((int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * (kPrBlock / 64) + wave;
   if (t >= Q.n_tiles) return;  // wave-uniform; the kernel has no workgroup barrier
   uint8_t* const wl = pr_lds + (size_t)wave * kPrWaveBytes;
   uint4* const pieces = (uint4*)wl;                               // [kPrPieces]
   uint32_t* const cur = (uint32_t*)(wl + kPrPieces * 16);         // [kPrT][4] next free entry of every list
+  uint32_t* const curmaj = cur + kPrT * 4;                        // [kPrT] ... of the major list
   // tile -> interval, positions, rows
-  int32_t a = 0, b = Q.n_iv;  // last interval with iv_tile0 <= t
-  while (b - a > 1) {
-    const int32_t m = (a + b) >> 1;
-    if (Q.iv_tile0[m] <= t) a = m; else b = m;
-  }
+  int64_t chunk;
+  const int32_t a = pr_tile_interval(Q, t, chunk);
   const int32_t ref = Q.iv_ref[a];
-  const int64_t chunk = t - Q.iv_tile0[a];
   const int32_t p0 = P.iv_start[a] + (int32_t)(chunk * kPrT);
   const int32_t iv_end = P.iv_end[a];
   const int32_t pend = iv_end - p0 < kPrT ? iv_end : p0 + kPrT;  // the tile is [p0, pend)
   const int32_t n_pos = pend - p0;
   const int64_t R0 = P.iv_row[a] + chunk * kPrT;
-  const unsigned long long off0 = Q.off[4 * R0], off1 = Q.off[4 * (R0 + n_pos)];
-  const uint32_t n_tile = (uint32_t)(off1 - off0 > 0xffffffffull ? 0xffffffffull : off1 - off0);
-  // lane k < 32 holds position k's state: its four lists inside the tile's stretch of the
-  // output, which of them is the longest ("major": it gets the cheap path), the major list's
-  // cursor (v_cur) and base code (v_maj).  The other cursors live in LDS.
+  const unsigned long long off0 = pr_off(Q, 4 * R0), off1 = pr_off(Q, 4 * (R0 + n_pos));
+  if (off1 - off0 > 600000000ull) {  // 6 x entry index must fit 32 bits (a tile this deep: 18 M reads on 32 positions)
+    atomicMin(Q.bad_row, (int32_t)(R0 > 0x7ffffffe ? 0x7ffffffe : R0));
+    return;
+  }
+  const uint32_t n_tile = (uint32_t)(off1 - off0);
+  // lane k < 32 sets up position k: its four lists inside the tile's stretch of the output and
+  // which of them is the longest ("major": it gets the cheap path).  The cursors (next free
+  // entry of every list) live in LDS: curmaj[k] for the major list, cur[k][e] for the others.
   const int pl = lane & (kPrT - 1);
   const bool active = lane < kPrT && pl < n_pos;
   uint32_t lbase[4] = {0, 0, 0, 0}, llen[4] = {0, 0, 0, 0};
   if (active) {
     unsigned long long o[5];
 #pragma unroll
-    for (int e = 0; e < 5; e++) o[e] = Q.off[4 * (R0 + pl) + e];
+    for (int e = 0; e < 5; e++) o[e] = pr_off(Q, 4 * (R0 + pl) + e);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       lbase[e] = (uint32_t)(o[e] - off0);
@@ -1289,114 +1323,150 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
 #pragma unroll
   for (uint32_t e = 1; e < 4; e++)
     if (llen[e] > sel4(llen, maj)) maj = e;
-  uint32_t v_cur = sel4(lbase, maj);
   const uint32_t v_maj = 1u << maj;  // Seq8 code of the major base (fasta.go:50-62)
   if (lane < kPrT) {
+    curmaj[pl] = sel4(lbase, maj);
 #pragma unroll
     for (int e = 0; e < 4; e++) cur[pl * 4 + e] = lbase[e];
   }
-  uint8_t* const gout = (uint8_t*)Q.out + off0 * 6;  // the tile's lists are one stretch of the output
+  // the tile's lists are one stretch of the output, addressed from a scalar base
+  const unsigned long long off0s = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off0 >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off0);
+  uint8_t* const gout = (uint8_t*)Q.out + off0s * 6;
 
-  // records of the reference that can cover the tile: pos in (p0 - max_span, pend)
+  // records of the reference that can cover the tile: pos in (p0 - max_span, pend), the first
+  // of them found by per_read_plan_kernel
   const int64_t hi = P.ref_first[ref + 1];
-  int64_t want = (int64_t)p0 - P.max_span + 1;
-  if (want < 0) want = 0;
-  const int64_t lo = first_at_or_after(P, P.ref_first[ref], hi, want);
+  const int64_t lo = Q.tile_lo[t];
   const uint4* cores4 = (const uint4*)P.cores;
   const uint32_t minq = (uint32_t)P.min_base_qual;
 
-  for (int64_t i = lo; i < hi;) {
-    // ---- phase 1: lane = record i + lane -> pieces
-    const bool have = i + lane < hi;
-    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-    if (have) {
-      c0 = cores4[2 * (i + lane)];
-      c1 = cores4[2 * (i + lane) + 1];
-    }
-    const int32_t pos = (int32_t)c0.x;
-    const uint32_t aux = c0.y >> 24, n_cigar = c0.z & 0xffffu, span = c0.z >> 16, l_seq = c0.w & 0xffffu,
-                   qdelta = c0.w >> 16;
-    // records are sorted: once one starts behind the tile, so does every later one
-    const bool last_batch = __builtin_amdgcn_ballot_w64(!have || pos >= pend) != 0;
-    // record-level tests (pileup.go:691, :717-729) were folded into AUX_KEEP by the packer
-    const bool rel = have && (aux & AUX_KEEP) && pos < pend && (int64_t)pos + span > (int64_t)p0;
-    const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)c1.x * 8);
-    uint32_t n_mine = 0;
-    if (rel) {
-      if (aux & AUX_SIMPLE) {
-        n_mine = 1;
-      } else {
-        int32_t r = pos;
-        for (uint32_t k = 0; k < n_cigar && r < pend; k++) {
-          const uint32_t w = k == 0 ? c1.y : k == 1 ? c1.z : k == 2 ? c1.w : cg[k];
-          const uint32_t op = w & 15u;
-          const int32_t len = (int32_t)(w >> 4);
-          if (op == 0) {
-            if (len > 0 && r + len > p0) n_mine++;   // r < pend holds
-            r += len;
-          } else if (op == 2 || op == 3) {
-            r += len;
-          } else if (op != 1 && op != 4 && op != 5) {
-            break;
-          }
-        }
-      }
-    }
-    const uint32_t incl = wave_inclusive_scan(n_mine);
-    // records whose pieces fit the list this round (a record has at most kPrT pieces)
-    const unsigned long long fit = __builtin_amdgcn_ballot_w64(incl <= (uint32_t)kPrPieces);
-    const int n_take = fit == ~0ull ? 64 : __builtin_ctzll(~fit);
-    const uint32_t n_pieces = (uint32_t)__builtin_amdgcn_readlane((int)incl, n_take - 1);
-    if (rel && lane < n_take && n_mine) {
-      uint32_t slot = incl - n_mine;
-      const uint32_t dz = qdelta | (((n_cigar + 1u) >> 1) << 16);
-      const uint32_t dw = l_seq | (((aux >> AUX_STRAND_SHIFT) & 3u) << 16);
-      if (aux & AUX_SIMPLE) {
-        const int32_t pa = pos > p0 ? pos - p0 : 0;
-        const int32_t pb = ((int64_t)pos + span < (int64_t)pend ? pos + (int32_t)span : pend) - p0;
-        pieces[slot] = make_uint4(c1.x, ((uint32_t)(p0 - pos) & 0xfffffu) | ((uint32_t)pa << 20) | ((uint32_t)pb << 26), dz, dw);
-      } else {
-        int32_t r = pos, qi = 0;
-        for (uint32_t k = 0; k < n_cigar && r < pend; k++) {
-          const uint32_t w = k == 0 ? c1.y : k == 1 ? c1.z : k == 2 ? c1.w : cg[k];
-          const uint32_t op = w & 15u;
-          const int32_t len = (int32_t)(w >> 4);
-          if (op == 0) {
-            if (len > 0 && r + len > p0) {
-              const int32_t pa = r > p0 ? r - p0 : 0;
-              const int32_t pb = (r + len < pend ? r + len : pend) - p0;
-              pieces[slot++] = make_uint4(c1.x, ((uint32_t)(qi + p0 - r) & 0xfffffu) | ((uint32_t)pa << 20) | ((uint32_t)pb << 26), dz, dw);
+  uint32_t n_q = 0;  // pieces waiting in the list
+  uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0;  // ReadCore of record i + lane, loaded a round ahead
+  if (lo + lane < hi) {
+    nx0 = cores4[2 * (lo + lane)];
+    nx1 = cores4[2 * (lo + lane) + 1];
+  }
+  for (int64_t i = lo;;) {
+    // ---- phase 1: lane = record i + lane; its pieces join the list
+    bool last = true;
+    int n_take = 64;
+    if (i < hi) {
+      const bool have = i + lane < hi;
+      const uint4 c0 = nx0, c1 = nx1;
+      const int32_t pos = (int32_t)c0.x;
+      const uint32_t aux = c0.y >> 24, n_cigar = c0.z & 0xffffu, span = c0.z >> 16, l_seq = c0.w & 0xffffu,
+                     qdelta = c0.w >> 16;
+      // records are sorted: once one starts behind the tile, so does every later one
+      const bool last_batch = __builtin_amdgcn_ballot_w64(!have || pos >= pend) != 0;
+      // record-level tests (pileup.go:691, :717-729) were folded into AUX_KEEP by the packer
+      const bool rel = have && (aux & AUX_KEEP) && pos < pend && (int64_t)pos + span > (int64_t)p0;
+      const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)c1.x * 8);
+      uint32_t n_mine = 0;
+      if (rel) {
+        if (aux & AUX_SIMPLE) {
+          n_mine = 1;
+        } else {
+          int32_t r = pos;
+          for (uint32_t k = 0; k < n_cigar && r < pend; k++) {
+            const uint32_t w = k == 0 ? c1.y : k == 1 ? c1.z : k == 2 ? c1.w : cg[k];
+            const uint32_t op = w & 15u;
+            const int32_t len = (int32_t)(w >> 4);
+            if (op == 0) {
+              if (len > 0 && r + len > p0) n_mine++;   // r < pend holds
+              r += len;
+            } else if (op == 2 || op == 3) {
+              r += len;
+            } else if (op != 1 && op != 4 && op != 5) {
+              break;
             }
-            r += len; qi += len;
-          } else if (op == 1 || op == 4) {
-            qi += len;
-          } else if (op == 2 || op == 3) {
-            r += len;
-          } else if (op != 5) {
-            break;
           }
         }
       }
+      const uint32_t incl = wave_inclusive_scan(n_mine);
+      // records whose pieces still fit the list (fewer than 64 wait in it, a record has at
+      // most kPrT: at least one record always fits)
+      const unsigned long long fit = __builtin_amdgcn_ballot_w64(n_q + incl <= (uint32_t)kPrPieces);
+      n_take = fit == ~0ull ? 64 : __builtin_ctzll(~fit);
+      if (rel && lane < n_take && n_mine) {
+        uint32_t slot = n_q + incl - n_mine;
+        const uint32_t dz = qdelta | (((n_cigar + 1u) >> 1) << 16);
+        const uint32_t dw = l_seq | (((aux >> AUX_STRAND_SHIFT) & 3u) << 16);
+        if (aux & AUX_SIMPLE) {
+          const int32_t pa = pos > p0 ? pos - p0 : 0;
+          const int32_t pb = ((int64_t)pos + span < (int64_t)pend ? pos + (int32_t)span : pend) - p0;
+          pieces[slot] = make_uint4(c1.x, ((uint32_t)(p0 - pos) & 0xfffffu) | ((uint32_t)pa << 20) | ((uint32_t)pb << 26), dz, dw);
+        } else {
+          int32_t r = pos, qi = 0;
+          for (uint32_t k = 0; k < n_cigar && r < pend; k++) {
+            const uint32_t w = k == 0 ? c1.y : k == 1 ? c1.z : k == 2 ? c1.w : cg[k];
+            const uint32_t op = w & 15u;
+            const int32_t len = (int32_t)(w >> 4);
+            if (op == 0) {
+              if (len > 0 && r + len > p0) {
+                const int32_t pa = r > p0 ? r - p0 : 0;
+                const int32_t pb = (r + len < pend ? r + len : pend) - p0;
+                pieces[slot++] = make_uint4(c1.x, ((uint32_t)(qi + p0 - r) & 0xfffffu) | ((uint32_t)pa << 20) | ((uint32_t)pb << 26), dz, dw);
+              }
+              r += len; qi += len;
+            } else if (op == 1 || op == 4) {
+              qi += len;
+            } else if (op == 2 || op == 3) {
+              r += len;
+            } else if (op != 5) {
+              break;
+            }
+          }
+        }
+      }
+      n_q += (uint32_t)__builtin_amdgcn_readlane((int)incl, n_take - 1);
+      last = last_batch && n_take == 64;
+      __builtin_amdgcn_wave_barrier();
+      if (!last) {  // the next round's records, in flight while this round's pieces are worked on
+        nx0 = nx1 = make_uint4(0, 0, 0, 0);
+        if (i + n_take + lane < hi) {
+          nx0 = cores4[2 * (i + n_take + lane)];
+          nx1 = cores4[2 * (i + n_take + lane) + 1];
+        }
+      }
     }
-    __builtin_amdgcn_wave_barrier();
 
-    // ---- phase 2: lane = piece
-    for (uint32_t pc = 0; pc < n_pieces; pc += 64) {
-      const bool mine = pc + lane < n_pieces;
+    // ---- phase 2: lane = piece; whole chunks of 64, the rest waits for the next records
+    uint32_t pc = 0;
+    for (; last ? pc < n_q : pc + 64 <= n_q; pc += 64) {
+      // No cursor may stand behind the tile's stretch (it would if a list outgrew the count that
+      // sized it): a chunk moves a cursor by at most 64 entries and the output buffer ends in
+      // that much slack, so checking here, once per chunk, keeps every store inside the buffer.
+      {
+        bool over = false;
+        if (lane < kPrT) {
+          const uint4 c4 = *(const uint4*)(cur + 4 * pl);
+          const uint32_t cmx = curmaj[pl];
+          over = c4.x > n_tile || c4.y > n_tile || c4.z > n_tile || c4.w > n_tile || cmx > n_tile;
+        }
+        if (__builtin_amdgcn_ballot_w64(over)) {
+          atomicMin(Q.bad_row, (int32_t)(R0 > 0x7ffffffe ? 0x7ffffffe : R0));
+          return;
+        }
+      }
+      const bool mine = pc + lane < n_q;
       uint4 d = make_uint4(0, 0, 0, 0);
       if (mine) d = pieces[pc + lane];
       const int32_t x0 = ((int32_t)(d.y << 12)) >> 12;   // read index under tile position 0 (may be < 0)
       const int32_t pa = (int32_t)((d.y >> 20) & 63u), pb = (int32_t)(d.y >> 26);  // valid tile positions [pa, pb)
-      const uint32_t pl_seq = d.w & 0xffffu;
+      const uint32_t w01base = (uint32_t)x0 + ((d.w & 0xffffu) << 16);  // + k: {index in read, read length}
       const uint32_t w2hi = ((d.w >> 16) & 3u) << 8;
       const uint8_t* rb = P.blob + (uint64_t)d.x * 8;
       // 32 bases under the tile: nibbles x0 .. x0+31 of the packed bases
       uint32_t B[4];
       {
         const uint32_t* bp = (const uint32_t*)(rb + (size_t)(d.z >> 16) * 8) + (x0 >> 3);
-        uint32_t r[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) r[j] = bp[j];
+        uint32_t r[5];  // one 16-byte and one 4-byte load (4-byte aligned)
+        {
+          const u32x4a v = *(const u32x4a*)bp;
+          r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+          r[4] = bp[4];
+        }
         const uint32_t sh = ((uint32_t)x0 & 7u) * 4u;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1409,59 +1479,72 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
       {
         const uint32_t* qp = (const uint32_t*)(rb + 8ull * (d.z & 0xffffu)) + (x0 >> 2);
         uint32_t r[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) r[j] = qp[j];
+        {
+          const u32x4a v = *(const u32x4a*)qp, w = *(const u32x4a*)(qp + 4);
+          r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+          r[4] = w.x; r[5] = w.y; r[6] = w.z; r[7] = w.w;
+          r[8] = qp[8];
+        }
         const uint32_t sh = ((uint32_t)x0 & 3u) * 8u;
 #pragma unroll
         for (int j = 0; j < 8; j++) Qv[j] = __builtin_amdgcn_alignbit(r[j + 1], r[j], sh);
       }
       uint32_t clipped = 0;  // tile positions whose qual clipQuals sets to 2 (pileup_support.go:47-69)
       if (CLIP) {
-        if (2 * P.clip >= (int32_t)pl_seq) clipped = 0xffffffffu;
-        else clipped = bit_range(0, P.clip - x0) | bit_range((int32_t)pl_seq - P.clip - x0, 32);
+        const int32_t pl_seq = (int32_t)(d.w & 0xffffu);
+        if (2 * P.clip >= pl_seq) clipped = 0xffffffffu;
+        else clipped = bit_range(0, P.clip - x0) | bit_range(pl_seq - P.clip - x0, 32);
       }
 #pragma unroll 1
       for (int j = 0; j < kPrT / 8; j++) {
         const uint32_t Bj = B[0], Q0 = Qv[0], Q1 = Qv[1];
+        // the 8 major cursors of the group (the same value in every lane)
+        uint32_t cm[8];
+        {
+          const uint4 c03 = *(const uint4*)(curmaj + 8 * j), c47 = *(const uint4*)(curmaj + 8 * j + 4);
+          cm[0] = c03.x; cm[1] = c03.y; cm[2] = c03.z; cm[3] = c03.w;
+          cm[4] = c47.x; cm[5] = c47.y; cm[6] = c47.z; cm[7] = c47.w;
+        }
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) {
           const int k = 8 * j + kk;
           const uint32_t nib = (Bj >> (4 * kk)) & 15u;
           uint32_t q = ((kk < 4 ? Q0 : Q1) >> (8 * (kk & 3))) & 255u;
           if (CLIP) q = (clipped >> k) & 1u ? 2u : q;
-          const bool qok = q >= minq;
           const uint32_t s_maj = (uint32_t)__builtin_amdgcn_readlane((int)v_maj, k);
-          const bool is_major = nib == s_maj && qok;
-          const unsigned long long M = __builtin_amdgcn_ballot_w64(is_major);
-          const unsigned long long Pm = __builtin_amdgcn_ballot_w64(nib != 0 && qok);
-          const uint32_t w01 = (uint32_t)(x0 + k) | (pl_seq << 16);
+          const unsigned long long Qm = __builtin_amdgcn_ballot_w64(q >= minq);
+          const unsigned long long M = __builtin_amdgcn_ballot_w64(nib == s_maj) & Qm;
+          const unsigned long long Pm = __builtin_amdgcn_ballot_w64(nib != 0) & Qm;
+          const uint32_t w01 = w01base + (uint32_t)k;
           const uint32_t w2 = q | w2hi;
-          if (M) {
-            const uint32_t s_cur = (uint32_t)__builtin_amdgcn_readlane((int)v_cur, k);
-            if (is_major) {
-              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
-              pr_put(gout, n_tile, s_cur + rank, w01, w2);
-            }
-            v_cur = lane == k ? s_cur + (uint32_t)__builtin_popcountll(M) : v_cur;
+          {
+            const uint32_t slot = cm[kk] + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+            if (nib == s_maj && q >= minq) pr_put(gout, slot, w01, w2);
+            cm[kk] += (uint32_t)__builtin_popcountll(M);
           }
           if (Pm != M) {
             // other listed bases (Seq8ToEnumTable, pileup/common.go:66: 1,2,4,8 -> A,C,G,T; anything
-            // else is X: counted, never listed, pileup.go:239-240)
-            const bool minor = nib != 0 && qok && !is_major && (nib & (nib - 1)) == 0;
-            const uint32_t e = (nib >> 1) - (nib >> 3);
-#pragma unroll
-            for (uint32_t e2 = 0; e2 < 4; e2++) {
-              const unsigned long long Me = __builtin_amdgcn_ballot_w64(minor && e == e2);
-              if (Me) {
-                const uint32_t c = cur[k * 4 + e2];
-                if (minor && e == e2) {
-                  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Me, 0u));
-                  pr_put(gout, n_tile, c + rank, w01, w2);
-                  if (rank == 0) cur[k * 4 + e2] = c + (uint32_t)__builtin_popcountll(Me);
-                }
+            // else is X: counted, never listed, pileup.go:239-240).  One base code per round,
+            // the lowest waiting lane's: nearly always a single round.
+            const bool minor = nib != 0 && nib != s_maj && q >= minq && (nib & (nib - 1u)) == 0;
+            unsigned long long Mm = __builtin_amdgcn_ballot_w64(minor);
+            while (Mm) {
+              const uint32_t nib1 = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)__builtin_ctzll(Mm));
+              const unsigned long long Me = __builtin_amdgcn_ballot_w64(nib == nib1) & Mm;
+              uint32_t* const ce = cur + k * 4 + ((nib1 >> 1) - (nib1 >> 3));
+              const uint32_t c = *ce;
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Me, 0u));
+              if (minor && nib == nib1) {
+                pr_put(gout, c + rank, w01, w2);
+                if (rank == 0) *ce = c + (uint32_t)__builtin_popcountll(Me);
               }
+              Mm &= ~Me;
             }
           }
+        }
+        if (lane == 0) {
+          *(uint4*)(curmaj + 8 * j) = make_uint4(cm[0], cm[1], cm[2], cm[3]);
+          *(uint4*)(curmaj + 8 * j + 4) = make_uint4(cm[4], cm[5], cm[6], cm[7]);
         }
         // next 8 positions
         B[0] = B[1]; B[1] = B[2]; B[2] = B[3];
@@ -1469,8 +1552,16 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
         for (int x = 0; x < 6; x++) Qv[x] = Qv[x + 2];
       }
     }
+    if (last) break;
+    // what is left (fewer than 64 pieces) moves to the front of the list
+    if (pc > 0 && pc < n_q) {
+      uint4 d = make_uint4(0, 0, 0, 0);
+      if (pc + lane < n_q) d = pieces[pc + lane];
+      __builtin_amdgcn_wave_barrier();
+      if (pc + lane < n_q) pieces[lane] = d;
+    }
+    n_q -= pc;
     __builtin_amdgcn_wave_barrier();
-    if (last_batch && n_take == 64) break;
     i += n_take;
   }
   // the lists must be exactly as long as the counts said
@@ -1478,7 +1569,7 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
     bool complete = true;
 #pragma unroll
     for (uint32_t e = 0; e < 4; e++) {
-      const uint32_t endc = e == maj ? v_cur : cur[pl * 4 + e];
+      const uint32_t endc = e == maj ? curmaj[pl] : cur[pl * 4 + e];
       complete = complete && endc == lbase[e] + llen[e];
     }
     if (!complete) {
@@ -1488,20 +1579,18 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
   }
 }
 
-void launch_tile_scan(const uint32_t* rows, unsigned long long* a, int64_t n, unsigned long long* tile_sum,
-                      hipStream_t s) {
+void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned long long* tile_sum, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, rows, a, n, tile_sum);
-}
-void launch_tile_add(unsigned long long* a, int64_t n, const unsigned long long* tile_base, hipStream_t s) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(tile_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, tile_base);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, rows, off32, n, tile_sum);
 }
 int per_read_tile_positions() { return kPrT; }
 void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s) {
   if (Q.n_tiles == 0) return;
+  hipLaunchKernelGGL(per_read_plan_kernel, dim3((unsigned)((Q.n_tiles + 255) / 256)), dim3(256), 0, s, P, Q,
+                     (int32_t*)Q.tile_lo);
   const size_t lds = (size_t)kPrWaveBytes * (kPrBlock / 64);
-  const dim3 grid((unsigned)((Q.n_tiles + kPrBlock / 64 - 1) / (kPrBlock / 64))), block(kPrBlock);
+  const int64_t n_blocks = (Q.n_tiles + kPrBlock / 64 - 1) / (kPrBlock / 64);
+  const dim3 grid((unsigned)((n_blocks + 7) / 8 * 8)), block(kPrBlock);
   if (P.clip > 0) hipLaunchKernelGGL((per_read_kernel<true>), grid, block, lds, s, P, Q);
   else hipLaunchKernelGGL((per_read_kernel<false>), grid, block, lds, s, P, Q);
 }

@@ -101,6 +101,8 @@ typedef struct bp_timing {
   float total_ms;    /* first launch to last completion */
   int64_t n_windows;
   int64_t n_items;   /* work items launched (windows x slices) */
+  float per_read_ms; /* the gather kernel of the last bp_per_read_build (0 before one) */
+  float per_read_scan_ms; /* ... and the scan of the counts before it (kernels + one host round trip) */
 } bp_timing;
 
 /* Library/runtime probe.  Fails (BP_EDEVICE) when no HIP device is usable: there is no

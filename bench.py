@@ -24,6 +24,10 @@ sys.path.insert(0, ROOT)
 
 CHR1_LEN = 248_956_422
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# secondary ceiling: the kernel issues one ds_add_u32 per aligned base;
+# a wave's ds_add_u32 (64 lanes x address + data) occupies a CU's LDS for 4 cycles = 16 lane
+# atomics per cycle and CU, x 256 CUs x 2.4 GHz
+LDS_ATOMIC_PEAK_G = 16 * 256 * 2.4
 
 
 def kept_aligned_bases(rb, opts_kw):
@@ -255,6 +259,8 @@ def main():
                                   if traffic else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": round(k_ms, 4), "plan_ms_avg": round(float(np.mean(plan_ms)), 4),
+                "lds_atomics": {"achieved": round(B / (k_ms * 1e-3) / 1e9, 1), "peak": LDS_ATOMIC_PEAK_G,
+                                "unit": "G ds_add_u32 lanes/s", "frac": round(B / (k_ms * 1e-3) / 1e9 / LDS_ATOMIC_PEAK_G, 4)},
             },
             "cpu_baseline": cpu,
             "setup": {"generate_s": round(gen_s, 1), "pack_and_h2d_s": round(submit_s, 2),

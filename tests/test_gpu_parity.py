@@ -1,4 +1,5 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU oracle (bit-exact)."""
+import ctypes as C
 import json
 import os
 import random
@@ -421,3 +422,51 @@ def test_per_read_lists_deep_and_fragmented(case):
         assert (off == woff).all()
         assert feats.tobytes() == wf.tobytes()
         assert len(feats) > 5_000
+
+
+def test_full_size_chr1_30x_properties():
+    """BASELINE.json configs[1] at its full size (chr1, 248,956,422 positions, 30x, per-strand
+    counts, DefaultOpts; what bench.py times), through properties that do not need the oracle
+    at that size: depth = the aligned bases counted on the host, every base in a count slot,
+    a second compute gives the same sums, linearity (the rows of two halves of the records add up
+    to the rows of all of them, row by row), and three windows of rows far into the contig
+    against the oracle run on just the reads that reach them."""
+    from bench import CHR1_LEN, kept_aligned_bases
+    L = CHR1_LEN
+    sb = synth.generate([(0, 0, L - 1000, 30.0)], threads=16)
+    rb = sb.to_record_batch()
+    bed = {0: [[0, L]]}
+    opts = O.make_opts()  # DefaultOpts, basestrand semantics (StrandNone dropped)
+    B = kept_aligned_bases(rb, dict(flag_exclude=0xF00, mapq=60))
+    with snp.PileupJob(opts, [L]) as job:
+        job.set_bed(bed)
+        job.submit(rb)
+        job.finish()
+        assert job.num_rows == L
+        sums = job.column_sums()
+        assert sums[0] == B
+        assert sum(sums[1:]) == sums[0]
+        job.compute()
+        assert job.column_sums() == sums
+        for w0 in (1_000, 123_456_789, L - 150_000):
+            lo = int(np.searchsorted(rb.pos, w0 - 600))
+            hi = int(np.searchsorted(rb.pos, w0 + 100_000))
+            _, wp, wv = O.pileup(opts, [L], {0: [[w0, w0 + 100_000]]}, rb.slice(lo, hi))
+            _, pos, vals = job.rows(w0, 100_000)
+            assert (pos == wp).all() and (vals == wv).all(), w0
+        # linearity: halves of the records, in two jobs, merged on the device
+        half = rb.n // 2
+        with snp.PileupJob(opts, [L]) as ja, snp.PileupJob(opts, [L]) as jb:
+            for j, part in ((ja, rb.slice(0, half)), (jb, rb.slice(half, rb.n))):
+                j.set_bed(bed)
+                j.submit(part)
+                j.finish()
+            ptr = C.c_void_p()
+            jb._check(jb.lib.bp_rows_device(jb.h, C.byref(ptr)))
+            ja.rows_accumulate(0, L, ptr.value)
+            assert ja.column_sums() == sums
+            step = 20_000_000
+            for r0 in range(0, L, step):
+                n = min(step, L - r0)
+                assert (ja.rows(r0, n)[2] == job.rows(r0, n)[2]).all(), r0
+    sb.close()

@@ -86,6 +86,13 @@ def main():
     if "c1s" in which:
         ok &= run("30x 20 Mb, stitched min-base-qual 20", [(0, 0, L - 1000, 30.0)], {0: [[0, L]]}, [L],
                   O.make_opts(stitch=1, min_base_qual=20), 2_000_000)
+    LF = 248_956_422  # the bench workload's contig with the other option sets
+    if "c2q" in which:
+        ok &= run("30x chr1, min-base-qual 20 clip 5", [(0, 0, LF - 1000, 30.0)], {0: [[0, LF]]}, [LF],
+                  O.make_opts(min_base_qual=20, clip=5), 1_000_000)
+    if "c2s" in which:
+        ok &= run("30x chr1, stitched min-base-qual 20", [(0, 0, LF - 1000, 30.0)], {0: [[0, LF]]}, [LF],
+                  O.make_opts(stitch=1, min_base_qual=20), 1_000_000)
     if "c5" in which:
         ok &= run_per_read("c5 60x 20 Mb, per-read lists (-cols dpref,quals)", L, 60.0,
                            O.make_opts(min_base_qual=13), 200_000)

@@ -6,7 +6,10 @@
 // EndLine turns the trailing tab into a newline.
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 #include "bio_host.h"
@@ -27,27 +30,36 @@ class Sink {
  public:
   explicit Sink(bool bgzf, int level = Z_DEFAULT_COMPRESSION, int threads = 4)
       : bgzf_(bgzf), level_(level), threads_(threads < 1 ? 1 : threads) {}
-  ~Sink() { if (f_) fclose(f_); }
+  ~Sink() {
+    StopThread();
+    if (f_) fclose(f_);
+  }
   std::string Open(const std::string& path) {
     path_ = path;
     f_ = fopen(path.c_str(), "wb");
     if (!f_) return "open " + path + ": cannot create";
     setvbuf(f_, nullptr, _IOFBF, 4 << 20);
+    th_ = std::thread([this] { Run(); });
     return "";
   }
-  std::string Write(const char* p, size_t n) {
-    if (!bgzf_) {
-      if (fwrite(p, 1, n, f_) != n) return "write " + path_ + ": short write";
-      return "";
-    }
-    pend_.append(p, n);
-    if (pend_.size() >= kBlock * kBatch * (size_t)threads_) return Compress(false);
+  // Text is handed to a thread of the sink's own (file writes and BGZF compression then
+  // overlap the rendering of the next rows); at most kMaxQueued bytes wait.  An error of an
+  // earlier write comes back from a later call or from Close.
+  std::string Write(std::string&& text) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return queued_ < kMaxQueued || !err_.empty(); });
+    if (!err_.empty()) return err_;
+    queued_ += text.size();
+    q_.push_back(std::move(text));
+    cv_.notify_all();
     return "";
   }
+  std::string Write(const char* p, size_t n) { return Write(std::string(p, n)); }
   std::string Close() {
-    std::string err;
-    if (bgzf_) {
-      err = Compress(true);
+    StopThread();
+    std::string err = err_;
+    if (bgzf_ && f_) {
+      if (err.empty()) err = Compress(true);
       static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
                                       0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (err.empty() && fwrite(eof, 1, 28, f_) != 28) err = "write " + path_ + ": short write";
@@ -56,6 +68,50 @@ class Sink {
     f_ = nullptr;
     return err;
   }
+
+ private:
+  static constexpr size_t kMaxQueued = 256u << 20;
+  void StopThread() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_ = true;
+      cv_.notify_all();
+    }
+    if (th_.joinable()) th_.join();
+  }
+  void Run() {
+    for (;;) {
+      std::string text;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty() || done_; });
+        if (q_.empty()) return;
+        text = std::move(q_.front());
+        q_.pop_front();
+      }
+      std::string e = WriteSync(text.data(), text.size());
+      std::unique_lock<std::mutex> lk(mu_);
+      queued_ -= text.size();
+      if (err_.empty() && !e.empty()) err_ = e;
+      cv_.notify_all();
+    }
+  }
+  std::string WriteSync(const char* p, size_t n) {
+    if (!bgzf_) {
+      if (fwrite(p, 1, n, f_) != n) return "write " + path_ + ": short write";
+      return "";
+    }
+    pend_.append(p, n);
+    if (pend_.size() >= kBlock * kBatch * (size_t)threads_) return Compress(false);
+    return "";
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::string> q_;
+  size_t queued_ = 0;
+  bool done_ = false;
+  std::string err_;
+  std::thread th_;
 
  private:
   static constexpr size_t kBlock = 0xff00;
@@ -135,9 +191,9 @@ class TsvBuf {
  private:
   void AppendUint(uint32_t v) {
     char t[12];
-    int n = 0;
-    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) buf_.push_back(t[--n]);
+    int n = 12;
+    do { t[--n] = (char)('0' + v % 10); v /= 10; } while (v);
+    buf_.append(t + n, (size_t)(12 - n));
   }
   std::string buf_;
 };
@@ -154,7 +210,7 @@ class Tsv {
     line_.str().clear();
     return err;
   }
-  std::string Append(const std::string& text) { return sink_.Write(text.data(), text.size()); }
+  std::string Append(std::string&& text) { return sink_.Write(std::move(text)); }
   std::string Close() { return sink_.Close(); }
 
  private:
@@ -264,11 +320,12 @@ class TsvWriter : public RowWriter {
         [&](int64_t first, int64_t last, int k) {
           rb[(size_t)k].str().clear();
           ab[(size_t)k].str().clear();
+          rb[(size_t)k].str().reserve((size_t)(last - first) * 40);
           return Render(ref_id, pos, vals, first, last, off, feats, rb[(size_t)k], ab[(size_t)k]);
         },
         [&](int k) {
-          std::string e = ref_.Append(rb[(size_t)k].str());
-          return e.empty() ? alt_.Append(ab[(size_t)k].str()) : e;
+          std::string e = ref_.Append(std::move(rb[(size_t)k].str()));
+          return e.empty() ? alt_.Append(std::move(ab[(size_t)k].str())) : e;
         });
   }
   std::string Render(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t first, int64_t last,
@@ -383,9 +440,10 @@ class BasestrandTsvWriter : public RowWriter {
         n, n_slots,
         [&](int64_t first, int64_t last, int k) {
           tb[(size_t)k].str().clear();
+          tb[(size_t)k].str().reserve((size_t)(last - first) * 48);
           return Render(ref_id, pos, vals, first, last, off, feats, tb[(size_t)k]);
         },
-        [&](int k) { return w_.Append(tb[(size_t)k].str()); });
+        [&](int k) { return w_.Append(std::move(tb[(size_t)k].str())); });
   }
   std::string Render(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t first, int64_t last,
                      const uint64_t* off, const bp_per_read* feats, TsvBuf& w_) const {

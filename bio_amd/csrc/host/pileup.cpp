@@ -15,6 +15,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -71,13 +74,13 @@ int64_t JobSpan() {
     long long v = atoll(e);
     if (v > 0) return v;
   }
-  return 1ll << 28;
+  return 1ll << 26;
 }
 
 // BIO_PILEUP_STATS=1 prints one line of counters and stage times to stderr at the end.
 struct Stats {
   int64_t records_read = 0, records_kept = 0, seeks = 0, jobs = 0;
-  double submit_s = 0, close_s = 0, total_s = 0;
+  double submit_s = 0, close_s = 0, close_wait_s = 0, total_s = 0;
 };
 double Now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -164,41 +167,79 @@ class Driver {
     return "";
   }
 
-  std::string CloseJob(const Job& j) {
-    // per-read lists can be long: smaller row chunks keep the host copies bounded
-    const int64_t chunk = per_read ? (kRowChunk >> 6) : kRowChunk;
-    std::vector<int32_t> ref((size_t)chunk), pos((size_t)chunk);
-    std::vector<uint32_t> vals((size_t)chunk * BP_ROW_U32);
+  // The handles of the open job leave the streams (the next job opens its own) and are closed
+  // by FinishJob, on the closer thread.
+  std::vector<bp_handle*> TakeHandles() {
+    std::vector<bp_handle*> hs;
+    for (Stream& s : streams) {
+      hs.push_back(s.h);
+      s.h = nullptr;
+    }
+    return hs;
+  }
+
+  // finishRef + the output conversion for one job (pileup.go:934-966): rows to the writers, in
+  // job order.  Frees the handles.
+  std::string FinishJob(const Job& j, std::vector<bp_handle*>& hs) {
+    std::string err = FinishJobRows(j, hs);
+    for (bp_handle*& h : hs) {
+      if (h) bp_destroy(h);
+      h = nullptr;
+    }
+    return err;
+  }
+
+  // One chunk of a job's rows on the host (with its per-read lists when those are asked for).
+  struct Chunk {
+    std::vector<int32_t> ref, pos;
+    std::vector<uint32_t> vals;
     std::vector<uint64_t> off;
     std::vector<bp_per_read> feats;
-    for (Stream& s : streams) {
-      if (bp_finish(s.h) != BP_OK) return HandleErr(s.h);
-      if (per_read && bp_per_read_build(s.h) != BP_OK) return HandleErr(s.h);
-      const int64_t n = bp_num_rows(s.h);
-      for (int64_t first = 0; first < n; first += chunk) {
-        const int64_t m = std::min(chunk, n - first);
-        if (bp_rows(s.h, first, m, ref.data(), pos.data(), vals.data()) != BP_OK) return HandleErr(s.h);
-        // rows of the padding belong to the neighbouring jobs
-        const int64_t lo = std::lower_bound(pos.begin(), pos.begin() + m, j.start) - pos.begin();
-        const int64_t hi = std::lower_bound(pos.begin(), pos.begin() + m, j.end) - pos.begin();
-        if (lo >= hi) continue;
-        const uint64_t* offp = nullptr;
-        const bp_per_read* featp = nullptr;
-        if (per_read) {
-          off.resize((size_t)(4 * (hi - lo) + 1));
-          if (bp_per_read_offsets(s.h, first + lo, hi - lo, off.data()) != BP_OK) return HandleErr(s.h);
-          feats.resize((size_t)(off.back() - off.front()));
-          if (bp_per_read_features(s.h, off.front(), off.back() - off.front(), feats.data()) != BP_OK)
-            return HandleErr(s.h);
-          offp = off.data();
-          featp = feats.data();
-        }
-        std::string err = s.writer->Write(ref.data() + lo, pos.data() + lo, vals.data() + lo * BP_ROW_U32, hi - lo,
-                                          offp, featp);
+    int64_t lo = 0, hi = 0;  // rows [lo, hi) of the chunk lie in the job's own range
+    std::string err;
+  };
+  void Fetch(bp_handle* h, const Job& j, int64_t first, int64_t m, Chunk* c) const {
+    c->err.clear();
+    c->ref.resize((size_t)m);
+    c->pos.resize((size_t)m);
+    c->vals.resize((size_t)m * BP_ROW_U32);
+    if (bp_rows(h, first, m, c->ref.data(), c->pos.data(), c->vals.data()) != BP_OK) { c->err = HandleErr(h); return; }
+    // rows of the padding belong to the neighbouring jobs
+    c->lo = std::lower_bound(c->pos.begin(), c->pos.begin() + m, j.start) - c->pos.begin();
+    c->hi = std::lower_bound(c->pos.begin(), c->pos.begin() + m, j.end) - c->pos.begin();
+    if (!per_read || c->lo >= c->hi) return;
+    c->off.resize((size_t)(4 * (c->hi - c->lo) + 1));
+    if (bp_per_read_offsets(h, first + c->lo, c->hi - c->lo, c->off.data()) != BP_OK) { c->err = HandleErr(h); return; }
+    c->feats.resize((size_t)(c->off.back() - c->off.front()));
+    if (bp_per_read_features(h, c->off.front(), c->off.back() - c->off.front(), c->feats.data()) != BP_OK)
+      c->err = HandleErr(h);
+  }
+
+  std::string FinishJobRows(const Job& j, std::vector<bp_handle*>& hs) {
+    // per-read lists can be long: smaller row chunks keep the host copies bounded
+    const int64_t chunk = per_read ? (kRowChunk >> 6) : kRowChunk;
+    Chunk buf[2];
+    for (size_t si = 0; si < streams.size(); si++) {
+      bp_handle* h = hs[si];
+      if (bp_finish(h) != BP_OK) return HandleErr(h);
+      if (per_read && bp_per_read_build(h) != BP_OK) return HandleErr(h);
+      const int64_t n = bp_num_rows(h);
+      // the copy of chunk k+1 from the device runs while chunk k is rendered
+      int cur = 0;
+      if (n > 0) Fetch(h, j, 0, std::min(chunk, n), &buf[0]);
+      for (int64_t first = 0; first < n; first += chunk, cur ^= 1) {
+        Chunk& c = buf[cur];
+        std::thread next;
+        if (first + chunk < n)
+          next = std::thread([&, first] { Fetch(h, j, first + chunk, std::min(chunk, n - first - chunk), &buf[cur ^ 1]); });
+        std::string err = c.err;
+        if (err.empty() && c.lo < c.hi)
+          err = streams[si].writer->Write(c.ref.data() + c.lo, c.pos.data() + c.lo, c.vals.data() + c.lo * BP_ROW_U32,
+                                          c.hi - c.lo, per_read ? c.off.data() : nullptr,
+                                          per_read ? c.feats.data() : nullptr);
+        if (next.joinable()) next.join();
         if (!err.empty()) return err;
       }
-      bp_destroy(s.h);
-      s.h = nullptr;
     }
     return "";
   }
@@ -216,6 +257,76 @@ class Driver {
   const BEDUnion& bed_;
   int ignore_strand_;
   int64_t bed_pad_ = 0;
+};
+
+// Jobs are closed (device computation, rows to the host, rendering, file writes) on a thread
+// of their own, in job order, while the main thread already reads the next job's records:
+// the reference overlaps its jobs across goroutines (pileup.go:862) and pays for the output
+// conversion serially at the end (output.go:143-148); here reading and output overlap instead.
+// At most one closed job waits behind the one being written, which bounds what stays resident
+// in HBM to three jobs.
+class Closer {
+ public:
+  explicit Closer(Driver* d) : drv_(d), th_([this] { Run(); }) {}
+  ~Closer() { Join(); }
+  // Blocks while a job is already waiting.  Returns the first error seen so far.
+  std::string Push(const Job& j, std::vector<bp_handle*> hs) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return q_.empty() || !err_.empty(); });
+    if (!err_.empty()) {
+      for (bp_handle* h : hs) if (h) bp_destroy(h);
+      return err_;
+    }
+    q_.push_back({j, std::move(hs)});
+    cv_.notify_all();
+    return "";
+  }
+  // Waits for everything pushed; returns the first error.
+  std::string Join() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_ = true;
+      cv_.notify_all();
+    }
+    if (th_.joinable()) th_.join();
+    return err_;
+  }
+  double busy_s() const { return busy_s_; }
+
+ private:
+  struct Item { Job job; std::vector<bp_handle*> hs; };
+  void Run() {
+    for (;;) {
+      Item it;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty() || done_; });
+        if (q_.empty()) return;
+        it = std::move(q_.front());
+      }
+      const double t0 = Now();
+      std::string e;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        e = err_;
+      }
+      if (e.empty()) e = drv_->FinishJob(it.job, it.hs);
+      else for (bp_handle* h : it.hs) if (h) bp_destroy(h);  // after an error: only free
+      busy_s_ += Now() - t0;
+      std::unique_lock<std::mutex> lk(mu_);
+      if (err_.empty()) err_ = e;
+      q_.pop_front();  // the slot frees only now: a waiting Push sees one job in flight
+      cv_.notify_all();
+    }
+  }
+  Driver* drv_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Item> q_;
+  std::string err_;
+  bool done_ = false;
+  double busy_s_ = 0;
+  std::thread th_;
 };
 
 }  // namespace
@@ -374,13 +485,14 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     open = e.empty();
     return e;
   };
+  Closer closer(&drv);
   auto close_job = [&]() -> std::string {
     double t0 = Now();
     std::string e = drv.Submit(&pend[0]);
     st.submit_s += Now() - t0;
     t0 = Now();
-    if (e.empty()) e = drv.CloseJob(jobs[ji]);
-    st.close_s += Now() - t0;
+    if (e.empty()) e = closer.Push(jobs[ji], drv.TakeHandles());
+    st.close_wait_s += Now() - t0;
     st.jobs++;
     open = false;
     ji++;
@@ -487,6 +599,13 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (!open && !(err = open_job()).empty()) break;
     err = close_job();
   }
+  {
+    const double t0 = Now();
+    const std::string e = closer.Join();
+    st.close_wait_s += Now() - t0;
+    st.close_s = closer.busy_s();
+    if (err.empty()) err = e;
+  }
   if (!err.empty()) {
     drv.Abort();
     return err;
@@ -499,9 +618,10 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
-            "submit_s=%.3f close_s=%.3f read_s=%.3f total_s=%.3f\n",
+            "submit_s=%.3f close_s=%.3f (on its own thread; the reader waited %.3f s for it) read_s=%.3f total_s=%.3f\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
-            index.loaded() ? 1 : 0, st.submit_s, st.close_s, st.total_s - st.submit_s - st.close_s, st.total_s);
+            index.loaded() ? 1 : 0, st.submit_s, st.close_s, st.close_wait_s,
+            st.total_s - st.submit_s - st.close_wait_s, st.total_s);
   return "";
 }
 

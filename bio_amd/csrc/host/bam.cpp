@@ -47,6 +47,10 @@ inline uint32_t U32(const uint8_t* p) {
 inline int32_t I32(const uint8_t* p) { return (int32_t)U32(p); }
 
 constexpr int kBatchBlocks = 256;  // up to 16 MiB inflated per refill
+// A batch's inflated bytes start kHead bytes into its buffer: the unconsumed tail of the previous
+// batch (normally part of one record) is copied in front of them and the buffers are swapped,
+// instead of appending 16 MiB to the old one.
+constexpr size_t kHead = 1 << 20;
 }  // namespace
 
 struct BamReader::Impl {
@@ -112,13 +116,13 @@ struct BamReader::Impl {
       if (fread(raw.data() + off, 1, (size_t)remaining, f) != (size_t)remaining) { B.err = "bgzf: truncated block"; return out; }
       size_t isize = U32(raw.data() + off + (size_t)remaining - 4);
       if (isize > 65536) { B.err = "bgzf: invalid uncompressed size"; return out; }
-      blks.push_back({off, (size_t)remaining - 8, isize, out_total});
-      if (isize) B.marks.emplace_back(out_total, block_at);
+      blks.push_back({off, (size_t)remaining - 8, isize, kHead + out_total});
+      if (isize) B.marks.emplace_back(kHead + out_total, block_at);
       pos = block_at + (uint64_t)total;
       out_total += isize;
     }
     B.end_pos = pos;
-    B.data.resize(out_total);
+    B.data.resize(kHead + out_total);
     if (blks.empty()) return out;
     int nt = std::min<int>(HostThreads(), (int)blks.size());
     std::vector<int> bad((size_t)nt, 0);
@@ -154,6 +158,30 @@ struct BamReader::Impl {
 
   // Appends the next batch behind the unconsumed tail and starts reading the one after it.
   std::string Refill() {
+    if (!file_eof && buf.size() - rd <= kHead) {
+      std::unique_ptr<Batch> b = next.valid() ? next.get() : ReadBatch(file_pos);
+      if (!b->err.empty()) return b->err;
+      const size_t tail = buf.size() - rd, at = kHead - tail;
+      if (tail) memcpy(b->data.data() + at, buf.data() + rd, tail);
+      // the mark of the block the tail starts in, and later ones, move with it
+      std::vector<std::pair<size_t, uint64_t>> nm;
+      if (tail) {
+        size_t k = 0;
+        while (k + 1 < marks.size() && marks[k + 1].first <= rd) k++;
+        for (; k < marks.size(); k++) nm.emplace_back((marks[k].first > rd ? marks[k].first - rd : 0) + at, marks[k].second);
+      }
+      nm.insert(nm.end(), b->marks.begin(), b->marks.end());
+      marks.swap(nm);
+      buf.swap(b->data);
+      rd = at;
+      file_pos = b->end_pos;
+      file_eof = b->eof;
+      if (!file_eof) {
+        const uint64_t pos = file_pos;
+        next = std::async(std::launch::async, [this, pos] { return ReadBatch(pos); });
+      }
+      return "";
+    }
     if (rd > 0) {
       buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)rd);
       // keep the mark of the block the tail starts in (its offset becomes 0) and later ones
@@ -166,9 +194,9 @@ struct BamReader::Impl {
     if (file_eof) return "";
     std::unique_ptr<Batch> b = next.valid() ? next.get() : ReadBatch(file_pos);
     if (!b->err.empty()) return b->err;
-    const size_t base = buf.size();
-    buf.insert(buf.end(), b->data.begin(), b->data.end());
-    for (const auto& mk : b->marks) marks.emplace_back(base + mk.first, mk.second);
+    const size_t base = buf.size();  // (a record longer than kHead: the slow way)
+    buf.insert(buf.end(), b->data.begin() + (ptrdiff_t)std::min(kHead, b->data.size()), b->data.end());
+    for (const auto& mk : b->marks) marks.emplace_back(base + mk.first - kHead, mk.second);
     file_pos = b->end_pos;
     file_eof = b->eof;
     if (!file_eof) {
@@ -230,8 +258,8 @@ std::string BamReader::Seek(uint64_t voffset) {
   m.marks.clear();
   std::string err = m.Refill();
   if (!err.empty()) return err;
-  if ((voffset & 0xffff) > m.buf.size()) return "bgzf: virtual offset past the end of its block";
-  m.rd = (size_t)(voffset & 0xffff);
+  if ((voffset & 0xffff) > m.buf.size() - m.rd) return "bgzf: virtual offset past the end of its block";
+  m.rd += (size_t)(voffset & 0xffff);
   return "";
 }
 

@@ -906,8 +906,8 @@ int bp_per_read_build(bp_handle* h) {
   h->n_feat = run;
   if (n_tiles)
     HIP_TRY(h, hipMemcpyAsync(h->d_pr_tiles.p, tiles.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, h->stream));
-  // + 64 entries of slack behind the last list (see the per-chunk cursor check in per_read_kernel)
-  if (int rc = ensure(h, h->d_pr_feat, ((size_t)run + 64) * sizeof(PerRead) + 256, 0)) return rc;
+  // + 128 entries of slack behind the last list (see the cursor check in per_read_kernel)
+  if (int rc = ensure(h, h->d_pr_feat, ((size_t)run + 128) * sizeof(PerRead) + 256, 0)) return rc;
   const size_t n_iv = h->iv_ref.size();
   if (int rc = ensure(h, h->d_iv_ref, n_iv * 4 + 256, 0)) return rc;
   if (n_iv) HIP_TRY(h, hipMemcpyAsync(h->d_iv_ref.p, h->iv_ref.data(), n_iv * 4, hipMemcpyHostToDevice, h->stream));

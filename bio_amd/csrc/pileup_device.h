@@ -124,7 +124,7 @@ static_assert(sizeof(PerRead) == 6, "PerRead must be 6 bytes");
 // cursors of the tile's lists.
 constexpr int kPrT = 32;          // positions per tile
 constexpr int kPrBlock = 256;     // threads per workgroup, one tile per wave
-constexpr int kPrPieces = 128;    // piece list per wave (16 bytes each); a record has at most kPrT
+constexpr int kPrPieces = 256;    // piece list per wave (16 bytes each); a record has at most kPrT
 constexpr int kPrWaveBytes = kPrPieces * 16 + kPrT * 16 + kPrT * 4;
 struct PerReadParams {
   const int32_t* iv_ref;          // [n_iv] reference of each flattened BED interval

@@ -1179,7 +1179,8 @@ __global__ void column_sums_kernel(const uint32_t* rows, int64_t n_rows, unsigne
 // the records that can reach it, 64 at a time:
 //   phase 1  lane = record.  The CIGAR walk leaves one 16-byte piece per M op that overlaps the
 //            tile, in (record, op) order, in a small LDS list (wave prefix sum for the slots).
-//   phase 2  lane = piece.  The 32 bases and quals under the tile are loaded with wide loads and
+//   phase 2  lane = piece, two chunks of 64 at a time, all loads before the first store.
+//            The 32 bases and quals under the tile are loaded with wide loads and
 //            realigned in registers (tile position k <-> nibble/byte k).  Then, position by
 //            position: a ballot of the lanes whose base is the position's most frequent one
 //            gives every such lane its rank (mbcnt) behind the position's cursor - lanes are
@@ -1274,6 +1275,13 @@ __global__ void per_read_plan_kernel(KernelParams P, PerReadParams Q, int32_t* t
   if (want < 0) want = 0;
   tile_lo[t] = (int32_t)first_at_or_after(P, P.ref_first[ref], P.ref_first[ref + 1], want);
 }
+
+// What a lane holds of its piece for one chunk: the 32 bases (nibble k = tile position k,
+// 0 outside the piece) and 32 quals under the tile, and the constant parts of its entries.
+struct PrChunk {
+  uint32_t B[4], Qv[8];
+  uint32_t w01base, w2hi, clipped;
+};
 
 template <bool CLIP>
 __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerReadParams Q) {
@@ -1384,7 +1392,7 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
         }
       }
       const uint32_t incl = wave_inclusive_scan(n_mine);
-      // records whose pieces still fit the list (fewer than 64 wait in it, a record has at
+      // records whose pieces still fit the list (fewer than 128 wait in it, a record has at
       // most kPrT: at least one record always fits)
       const unsigned long long fit = __builtin_amdgcn_ballot_w64(n_q + incl <= (uint32_t)kPrPieces);
       n_take = fit == ~0ull ? 64 : __builtin_ctzll(~fit);
@@ -1431,12 +1439,22 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
       }
     }
 
-    // ---- phase 2: lane = piece; whole chunks of 64, the rest waits for the next records
+    // more records first, while fewer than two chunks of pieces wait
+    if (!last && n_q < 128) {
+      i += n_take;
+      continue;
+    }
+
+    // ---- phase 2: lane = piece, two chunks of 64 at a time; the loads of both chunks are
+    // issued before the first store (loads and stores share the in-order vmcnt counter).  A
+    // tile of 32 positions at 60x has ~80 pieces: all its loads come before all its stores.
+    // (Measured: no faster than one chunk at a time; kept because it is no slower either and
+    // the wait for a chunk's loads no longer sits behind the previous chunk's stores.)
     uint32_t pc = 0;
-    for (; last ? pc < n_q : pc + 64 <= n_q; pc += 64) {
+    for (; last ? pc < n_q : pc + 128 <= n_q; pc += 128) {
       // No cursor may stand behind the tile's stretch (it would if a list outgrew the count that
-      // sized it): a chunk moves a cursor by at most 64 entries and the output buffer ends in
-      // that much slack, so checking here, once per chunk, keeps every store inside the buffer.
+      // sized it): two chunks move a cursor by at most 128 entries and the output buffer ends in
+      // that much slack, so checking here keeps every store inside the buffer.
       {
         bool over = false;
         if (lane < kPrT) {
@@ -1449,116 +1467,118 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
           return;
         }
       }
-      const bool mine = pc + lane < n_q;
-      uint4 d = make_uint4(0, 0, 0, 0);
-      if (mine) d = pieces[pc + lane];
-      const int32_t x0 = ((int32_t)(d.y << 12)) >> 12;   // read index under tile position 0 (may be < 0)
-      const int32_t pa = (int32_t)((d.y >> 20) & 63u), pb = (int32_t)(d.y >> 26);  // valid tile positions [pa, pb)
-      const uint32_t w01base = (uint32_t)x0 + ((d.w & 0xffffu) << 16);  // + k: {index in read, read length}
-      const uint32_t w2hi = ((d.w >> 16) & 3u) << 8;
-      const uint8_t* rb = P.blob + (uint64_t)d.x * 8;
-      // 32 bases under the tile: nibbles x0 .. x0+31 of the packed bases
-      uint32_t B[4];
-      {
-        const uint32_t* bp = (const uint32_t*)(rb + (size_t)(d.z >> 16) * 8) + (x0 >> 3);
-        uint32_t r[5];  // one 16-byte and one 4-byte load (4-byte aligned)
-        {
-          const u32x4a v = *(const u32x4a*)bp;
-          r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
-          r[4] = bp[4];
-        }
-        const uint32_t sh = ((uint32_t)x0 & 7u) * 4u;
+      PrChunk ch[2];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          B[j] = __builtin_amdgcn_alignbit(r[j + 1], r[j], sh);
-          B[j] &= bit_range(4 * (pa - 8 * j), 4 * (pb - 8 * j));  // positions outside the piece read as 0
+      for (int c = 0; c < 2; c++) {
+        PrChunk& C = ch[c];
+        const uint32_t at = pc + 64u * c;
+        uint4 d = make_uint4(0, 0, 0, 0);
+        if (at + lane < n_q) d = pieces[at + lane];
+        const int32_t x0 = ((int32_t)(d.y << 12)) >> 12;   // read index under tile position 0 (may be < 0)
+        const int32_t pa = (int32_t)((d.y >> 20) & 63u), pb = (int32_t)(d.y >> 26);  // valid tile positions [pa, pb)
+        C.w01base = (uint32_t)x0 + ((d.w & 0xffffu) << 16);  // + k: {index in read, read length}
+        C.w2hi = ((d.w >> 16) & 3u) << 8;
+        C.clipped = 0;  // tile positions whose qual clipQuals sets to 2 (pileup_support.go:47-69)
+        if (CLIP) {
+          const int32_t pl_seq = (int32_t)(d.w & 0xffffu);
+          if (2 * P.clip >= pl_seq) C.clipped = 0xffffffffu;
+          else C.clipped = bit_range(0, P.clip - x0) | bit_range(pl_seq - P.clip - x0, 32);
         }
-      }
-      // and the 32 quals: bytes x0 .. x0+31
-      uint32_t Qv[8];
-      {
-        const uint32_t* qp = (const uint32_t*)(rb + 8ull * (d.z & 0xffffu)) + (x0 >> 2);
-        uint32_t r[9];
-        {
-          const u32x4a v = *(const u32x4a*)qp, w = *(const u32x4a*)(qp + 4);
-          r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
-          r[4] = w.x; r[5] = w.y; r[6] = w.z; r[7] = w.w;
-          r[8] = qp[8];
-        }
-        const uint32_t sh = ((uint32_t)x0 & 3u) * 8u;
 #pragma unroll
-        for (int j = 0; j < 8; j++) Qv[j] = __builtin_amdgcn_alignbit(r[j + 1], r[j], sh);
+        for (int j = 0; j < 4; j++) C.B[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) C.Qv[j] = 0;
+        if (at < n_q) {  // wave-uniform: the second chunk of the last pair may not exist
+          const uint8_t* rb = P.blob + (uint64_t)d.x * 8;
+          // 32 bases under the tile: nibbles x0 .. x0+31 of the packed bases
+          const uint32_t* bp = (const uint32_t*)(rb + (size_t)(d.z >> 16) * 8) + (x0 >> 3);
+          const u32x4a bv = *(const u32x4a*)bp;  // one 16-byte and one 4-byte load (4-byte aligned)
+          const uint32_t b4 = bp[4];
+          // and the 32 quals: bytes x0 .. x0+31
+          const uint32_t* qp = (const uint32_t*)(rb + 8ull * (d.z & 0xffffu)) + (x0 >> 2);
+          const u32x4a qv = *(const u32x4a*)qp, qw = *(const u32x4a*)(qp + 4);
+          const uint32_t q8 = qp[8];
+          const uint32_t br[5] = {bv.x, bv.y, bv.z, bv.w, b4};
+          const uint32_t qr[9] = {qv.x, qv.y, qv.z, qv.w, qw.x, qw.y, qw.z, qw.w, q8};
+          const uint32_t shb = ((uint32_t)x0 & 7u) * 4u, shq = ((uint32_t)x0 & 3u) * 8u;
+#pragma unroll
+          for (int j = 0; j < 4; j++)  // positions outside the piece read as 0
+            C.B[j] = __builtin_amdgcn_alignbit(br[j + 1], br[j], shb) & bit_range(4 * (pa - 8 * j), 4 * (pb - 8 * j));
+#pragma unroll
+          for (int j = 0; j < 8; j++) C.Qv[j] = __builtin_amdgcn_alignbit(qr[j + 1], qr[j], shq);
+        }
       }
-      uint32_t clipped = 0;  // tile positions whose qual clipQuals sets to 2 (pileup_support.go:47-69)
-      if (CLIP) {
-        const int32_t pl_seq = (int32_t)(d.w & 0xffffu);
-        if (2 * P.clip >= pl_seq) clipped = 0xffffffffu;
-        else clipped = bit_range(0, P.clip - x0) | bit_range(pl_seq - P.clip - x0, 32);
-      }
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        if (pc + 64u * c >= n_q) break;
+        PrChunk C = ch[c];
 #pragma unroll 1
-      for (int j = 0; j < kPrT / 8; j++) {
-        const uint32_t Bj = B[0], Q0 = Qv[0], Q1 = Qv[1];
-        // the 8 major cursors of the group (the same value in every lane)
-        uint32_t cm[8];
-        {
-          const uint4 c03 = *(const uint4*)(curmaj + 8 * j), c47 = *(const uint4*)(curmaj + 8 * j + 4);
-          cm[0] = c03.x; cm[1] = c03.y; cm[2] = c03.z; cm[3] = c03.w;
-          cm[4] = c47.x; cm[5] = c47.y; cm[6] = c47.z; cm[7] = c47.w;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
-          const int k = 8 * j + kk;
-          const uint32_t nib = (Bj >> (4 * kk)) & 15u;
-          uint32_t q = ((kk < 4 ? Q0 : Q1) >> (8 * (kk & 3))) & 255u;
-          if (CLIP) q = (clipped >> k) & 1u ? 2u : q;
-          const uint32_t s_maj = (uint32_t)__builtin_amdgcn_readlane((int)v_maj, k);
-          const unsigned long long Qm = __builtin_amdgcn_ballot_w64(q >= minq);
-          const unsigned long long M = __builtin_amdgcn_ballot_w64(nib == s_maj) & Qm;
-          const unsigned long long Pm = __builtin_amdgcn_ballot_w64(nib != 0) & Qm;
-          const uint32_t w01 = w01base + (uint32_t)k;
-          const uint32_t w2 = q | w2hi;
+        for (int j = 0; j < kPrT / 8; j++) {
+          const uint32_t Bj = C.B[0], Q0 = C.Qv[0], Q1 = C.Qv[1];
+          // the 8 major cursors of the group (the same value in every lane)
+          uint32_t cm[8];
           {
-            const uint32_t slot = cm[kk] + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
-            if (nib == s_maj && q >= minq) pr_put(gout, slot, w01, w2);
-            cm[kk] += (uint32_t)__builtin_popcountll(M);
+            const uint4 c03 = *(const uint4*)(curmaj + 8 * j), c47 = *(const uint4*)(curmaj + 8 * j + 4);
+            cm[0] = c03.x; cm[1] = c03.y; cm[2] = c03.z; cm[3] = c03.w;
+            cm[4] = c47.x; cm[5] = c47.y; cm[6] = c47.z; cm[7] = c47.w;
           }
-          if (Pm != M) {
-            // other listed bases (Seq8ToEnumTable, pileup/common.go:66: 1,2,4,8 -> A,C,G,T; anything
-            // else is X: counted, never listed, pileup.go:239-240).  One base code per round,
-            // the lowest waiting lane's: nearly always a single round.
-            const bool minor = nib != 0 && nib != s_maj && q >= minq && (nib & (nib - 1u)) == 0;
-            unsigned long long Mm = __builtin_amdgcn_ballot_w64(minor);
-            while (Mm) {
-              const uint32_t nib1 = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)__builtin_ctzll(Mm));
-              const unsigned long long Me = __builtin_amdgcn_ballot_w64(nib == nib1) & Mm;
-              uint32_t* const ce = cur + k * 4 + ((nib1 >> 1) - (nib1 >> 3));
-              const uint32_t c = *ce;
-              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Me, 0u));
-              if (minor && nib == nib1) {
-                pr_put(gout, c + rank, w01, w2);
-                if (rank == 0) *ce = c + (uint32_t)__builtin_popcountll(Me);
+#pragma unroll
+          for (int kk = 0; kk < 8; kk++) {
+            const int k = 8 * j + kk;
+            const uint32_t nib = (Bj >> (4 * kk)) & 15u;
+            uint32_t q = ((kk < 4 ? Q0 : Q1) >> (8 * (kk & 3))) & 255u;
+            if (CLIP) q = (C.clipped >> k) & 1u ? 2u : q;
+            const uint32_t s_maj = (uint32_t)__builtin_amdgcn_readlane((int)v_maj, k);
+            const unsigned long long Qm = __builtin_amdgcn_ballot_w64(q >= minq);
+            const unsigned long long M = __builtin_amdgcn_ballot_w64(nib == s_maj) & Qm;
+            const unsigned long long Pm = __builtin_amdgcn_ballot_w64(nib != 0) & Qm;
+            const uint32_t w01 = C.w01base + (uint32_t)k;
+            const uint32_t w2 = q | C.w2hi;
+            {
+              const uint32_t slot = cm[kk] + __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+              if (nib == s_maj && q >= minq) pr_put(gout, slot, w01, w2);
+              cm[kk] += (uint32_t)__builtin_popcountll(M);
+            }
+            if (Pm != M) {
+              // other listed bases (Seq8ToEnumTable, pileup/common.go:66: 1,2,4,8 -> A,C,G,T; anything
+              // else is X: counted, never listed, pileup.go:239-240).  One base code per round,
+              // the lowest waiting lane's: nearly always a single round.
+              const bool minor = nib != 0 && nib != s_maj && q >= minq && (nib & (nib - 1u)) == 0;
+              unsigned long long Mm = __builtin_amdgcn_ballot_w64(minor);
+              while (Mm) {
+                const uint32_t nib1 = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)__builtin_ctzll(Mm));
+                const unsigned long long Me = __builtin_amdgcn_ballot_w64(nib == nib1) & Mm;
+                uint32_t* const ce = cur + k * 4 + ((nib1 >> 1) - (nib1 >> 3));
+                const uint32_t c0 = *ce;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Me, 0u));
+                if (minor && nib == nib1) {
+                  pr_put(gout, c0 + rank, w01, w2);
+                  if (rank == 0) *ce = c0 + (uint32_t)__builtin_popcountll(Me);
+                }
+                Mm &= ~Me;
               }
-              Mm &= ~Me;
             }
           }
-        }
-        if (lane == 0) {
-          *(uint4*)(curmaj + 8 * j) = make_uint4(cm[0], cm[1], cm[2], cm[3]);
-          *(uint4*)(curmaj + 8 * j + 4) = make_uint4(cm[4], cm[5], cm[6], cm[7]);
-        }
-        // next 8 positions
-        B[0] = B[1]; B[1] = B[2]; B[2] = B[3];
+          if (lane == 0) {
+            *(uint4*)(curmaj + 8 * j) = make_uint4(cm[0], cm[1], cm[2], cm[3]);
+            *(uint4*)(curmaj + 8 * j + 4) = make_uint4(cm[4], cm[5], cm[6], cm[7]);
+          }
+          // next 8 positions
+          C.B[0] = C.B[1]; C.B[1] = C.B[2]; C.B[2] = C.B[3];
 #pragma unroll
-        for (int x = 0; x < 6; x++) Qv[x] = Qv[x + 2];
+          for (int x = 0; x < 6; x++) C.Qv[x] = C.Qv[x + 2];
+        }
       }
     }
     if (last) break;
-    // what is left (fewer than 64 pieces) moves to the front of the list
+    // what is left (fewer than 128 pieces) moves to the front of the list
     if (pc > 0 && pc < n_q) {
-      uint4 d = make_uint4(0, 0, 0, 0);
-      if (pc + lane < n_q) d = pieces[pc + lane];
+      uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+      if (pc + lane < n_q) d0 = pieces[pc + lane];
+      if (pc + 64 + lane < n_q) d1 = pieces[pc + 64 + lane];
       __builtin_amdgcn_wave_barrier();
-      if (pc + lane < n_q) pieces[lane] = d;
+      if (pc + lane < n_q) pieces[lane] = d0;
+      if (pc + 64 + lane < n_q) pieces[64 + lane] = d1;
     }
     n_q -= pc;
     __builtin_amdgcn_wave_barrier();

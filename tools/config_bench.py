@@ -90,6 +90,9 @@ def main():
     if "c2q" in which:
         ok &= run("30x chr1, min-base-qual 20 clip 5", [(0, 0, LF - 1000, 30.0)], {0: [[0, LF]]}, [LF],
                   O.make_opts(min_base_qual=20, clip=5), 1_000_000)
+    if "c2m" in which:
+        ok &= run("30x chr1, min-base-qual 20", [(0, 0, LF - 1000, 30.0)], {0: [[0, LF]]}, [LF],
+                  O.make_opts(min_base_qual=20), 1_000_000)
     if "c2s" in which:
         ok &= run("30x chr1, stitched min-base-qual 20", [(0, 0, LF - 1000, 30.0)], {0: [[0, LF]]}, [LF],
                   O.make_opts(stitch=1, min_base_qual=20), 1_000_000)

@@ -162,6 +162,7 @@ def main():
         t_sum = 0
         if tail_rows:
             tt = torch.zeros(tail_rows * 11, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()  # the job copies on its own stream: the fill must be done first
             job.rows_export(own_rows, tail_rows, tt.data_ptr())
             t_sum = int(tt.view(-1, 11)[:, 0].to(torch.int64).sum().item())
         both = torch.tensor([sums[0] - t_sum, B], dtype=torch.int64, device=wire)

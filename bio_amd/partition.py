@@ -133,14 +133,22 @@ def exchange_boundaries(dist, torch, job, own_rows, tail_rows, tail, rank, world
     rows stay in HBM; "cpu" only for the host-side stand-in job of the CPU tests)."""
     if world_size > 1 and own_rows < tail:
         raise ValueError(f"partition of {own_rows} positions is shorter than the {tail}-row boundary tail")
+    # The job works on its own HIP stream and torch (and RCCL under it) on theirs; every hand-over
+    # between the two is a full synchronisation: the zero fill must be done before the export
+    # writes into the same buffer, and the gathered rows must have arrived before the add reads
+    # them (a collective returns once it is queued, not once it is done).
     send = torch.zeros(tail * 11, dtype=torch.int32, device=stage)
+    if stage == "cuda":
+        torch.cuda.synchronize()
     if tail_rows:
-        job.rows_export(own_rows, tail_rows, send.data_ptr())
+        job.rows_export(own_rows, tail_rows, send.data_ptr())  # returns when the copy is done
     wire = send if device == stage else send.to(device)
     got = [torch.empty_like(wire) for _ in range(world_size)]
     dist.all_gather(got, wire)
+    if device == "cuda":
+        torch.cuda.synchronize()
     if rank > 0:
         left = got[rank - 1] if device == stage else got[rank - 1].to(stage)
-        job.rows_accumulate(0, tail, left.data_ptr())
         if stage == "cuda":
             torch.cuda.synchronize()
+        job.rows_accumulate(0, tail, left.data_ptr())  # returns when the add is done

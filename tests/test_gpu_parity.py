@@ -308,6 +308,7 @@ def test_boundary_merge_on_device():
     for g in range(G - 1):
         own, tl = spans[g]
         buf = torch.zeros(tail * 11, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()  # the jobs work on their own streams
         jobs[g].rows_export(own, tl, buf.data_ptr())
         jobs[g + 1].rows_accumulate(0, tail, buf.data_ptr())
     got_pos = np.concatenate([jobs[g].rows(0, spans[g][0])[1] for g in range(G)])

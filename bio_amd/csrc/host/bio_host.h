@@ -190,6 +190,10 @@ class RowWriter {
   // points at entry off[0]); both NULL unless a per-read column set was requested.
   virtual std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                             const uint64_t* off, const bp_per_read* feats) = 0;
+  // Lines already rendered (on the device, bp_render_basestrand_tsv), appended as they are.
+  // A string to render into: one the sink has finished with (capacity kept, no fresh pages) if any.
+  virtual std::string SpareText() { return std::string(); }
+  virtual std::string WriteText(std::string&& text) { (void)text; return "pileup output: this format takes rows, not text"; }
   virtual std::string Close() = 0;
 };
 // ConvertPileupRowsToTSV (output.go:42-300): <prefix>.ref.tsv[.gz] + <prefix>.alt.tsv[.gz]

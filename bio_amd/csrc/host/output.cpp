@@ -55,6 +55,13 @@ class Sink {
     return "";
   }
   std::string Write(const char* p, size_t n) { return Write(std::string(p, n)); }
+  std::string Spare() {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (spare_.empty()) return std::string();
+    std::string s = std::move(spare_.back());
+    spare_.pop_back();
+    return s;
+  }
   std::string Close() {
     StopThread();
     std::string err = err_;
@@ -92,6 +99,10 @@ class Sink {
       std::string e = WriteSync(text.data(), text.size());
       std::unique_lock<std::mutex> lk(mu_);
       queued_ -= text.size();
+      if (spare_.size() < 4 && text.capacity() >= (1u << 20)) {  // large buffers go round again
+        text.clear();
+        spare_.push_back(std::move(text));
+      }
       if (err_.empty() && !e.empty()) err_ = e;
       cv_.notify_all();
     }
@@ -108,6 +119,7 @@ class Sink {
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<std::string> q_;
+  std::vector<std::string> spare_;
   size_t queued_ = 0;
   bool done_ = false;
   std::string err_;
@@ -211,6 +223,7 @@ class Tsv {
     return err;
   }
   std::string Append(std::string&& text) { return sink_.Write(std::move(text)); }
+  std::string Spare() { return sink_.Spare(); }
   std::string Close() { return sink_.Close(); }
 
  private:
@@ -430,6 +443,11 @@ class BasestrandTsvWriter : public RowWriter {
     }
   }
   static void AppendUint(std::string& s, uint32_t v) { s += std::to_string(v); s.push_back(','); }
+  std::string SpareText() override { return w_.Spare(); }
+  std::string WriteText(std::string&& text) override {
+    if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
+    return w_.Append(std::move(text));
+  }
   std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                     const uint64_t* off, const bp_per_read* feats) override {
     const bool per_read = (cols_ & kPerReadMask) != 0;

@@ -91,6 +91,12 @@ struct Job {
   PosType start, end;  // positions [start, end) of contig `ref`
 };
 
+// What closing a job needs besides its handles.
+struct JobRows {
+  int64_t row_lo = 0, row_hi = 0;  // the handle's rows [row_lo, row_hi) lie in the job's own range
+  bool device_text = false;        // the device renders the lines (bp_render_basestrand_tsv)
+};
+
 struct Stream {  // one output stream = one strand pass (pileup.go:1118-1128)
   int strand_req = BP_STRAND_NONE;
   std::unique_ptr<RowWriter> writer;
@@ -129,6 +135,10 @@ class Driver {
 
   std::vector<Stream> streams;
   bool per_read = false;  // a per-read column set is requested (pCtx.perReadNeeded)
+  // basestrand-tsv without per-read columns: the rows become text on the device
+  bool device_text = false;
+  const std::vector<const std::string*>* ref_seqs = nullptr;
+  JobRows open_rows;  // of the open job
 
   void SetPadding(int64_t bed_pad) { bed_pad_ = bed_pad; }
 
@@ -155,6 +165,27 @@ class Driver {
       const std::vector<PosType>& e = part.id_map[(size_t)j.ref];
       if (bp_set_bed(s.h, j.ref, e.data(), (int32_t)e.size()) != BP_OK) return HandleErr(s.h);
     }
+    // rows of the padding belong to the neighbouring jobs: BED positions of `part` before the
+    // job's start and before its end
+    const std::vector<PosType>& e = part.id_map[(size_t)j.ref];
+    auto before = [&](int64_t x) {
+      int64_t n = 0;
+      for (size_t k = 0; k + 1 < e.size(); k += 2)
+        n += std::max<int64_t>(0, std::min<int64_t>(e[k + 1], x) - e[k]);
+      return n;
+    };
+    open_rows = JobRows();
+    open_rows.row_lo = before(j.start);
+    open_rows.row_hi = before(j.end);
+    // The device writes the lines itself when every position of the job has a reference base
+    // (otherwise the host path reports the missing one, output.go:158).
+    const std::string* seq = ref_seqs && (size_t)j.ref < ref_seqs->size() ? (*ref_seqs)[(size_t)j.ref] : nullptr;
+    if (device_text && seq && e.size() >= 2 && (size_t)e.back() <= seq->size()) {
+      for (Stream& s : streams)
+        if (bp_set_ref_seq8(s.h, j.ref, e.front(), (const uint8_t*)seq->data() + e.front(), (int64_t)e.back() - e.front()) != BP_OK)
+          return HandleErr(s.h);
+      open_rows.device_text = true;
+    }
     return "";
   }
 
@@ -180,8 +211,8 @@ class Driver {
 
   // finishRef + the output conversion for one job (pileup.go:934-966): rows to the writers, in
   // job order.  Frees the handles.
-  std::string FinishJob(const Job& j, std::vector<bp_handle*>& hs) {
-    std::string err = FinishJobRows(j, hs);
+  std::string FinishJob(const Job& j, std::vector<bp_handle*>& hs, const JobRows& jr) {
+    std::string err = jr.device_text ? FinishJobText(hs, jr) : FinishJobRows(j, hs);
     for (bp_handle*& h : hs) {
       if (h) bp_destroy(h);
       h = nullptr;
@@ -213,6 +244,26 @@ class Driver {
     c->feats.resize((size_t)(c->off.back() - c->off.front()));
     if (bp_per_read_features(h, c->off.front(), c->off.back() - c->off.front(), c->feats.data()) != BP_OK)
       c->err = HandleErr(h);
+  }
+
+  // The lines come from the device, a chunk of rows at a time; the sink writes one chunk while
+  // the next is rendered and copied.
+  std::string FinishJobText(std::vector<bp_handle*>& hs, const JobRows& jr) {
+    for (size_t si = 0; si < streams.size(); si++) {
+      bp_handle* h = hs[si];
+      if (bp_finish(h) != BP_OK) return HandleErr(h);
+      for (int64_t first = jr.row_lo; first < jr.row_hi; first += kRowChunk) {
+        const int64_t m = std::min<int64_t>(kRowChunk, jr.row_hi - first);
+        size_t len = 0;
+        if (bp_render_basestrand_tsv(h, first, m, nullptr, 0, &len) != BP_OK) return HandleErr(h);
+        std::string text = streams[si].writer->SpareText();
+        text.resize(len);
+        if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
+        std::string err = streams[si].writer->WriteText(std::move(text));
+        if (!err.empty()) return err;
+      }
+    }
+    return "";
   }
 
   std::string FinishJobRows(const Job& j, std::vector<bp_handle*>& hs) {
@@ -270,14 +321,14 @@ class Closer {
   explicit Closer(Driver* d) : drv_(d), th_([this] { Run(); }) {}
   ~Closer() { Join(); }
   // Blocks while a job is already waiting.  Returns the first error seen so far.
-  std::string Push(const Job& j, std::vector<bp_handle*> hs) {
+  std::string Push(const Job& j, std::vector<bp_handle*> hs, const JobRows& jr) {
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [this] { return q_.empty() || !err_.empty(); });
     if (!err_.empty()) {
       for (bp_handle* h : hs) if (h) bp_destroy(h);
       return err_;
     }
-    q_.push_back({j, std::move(hs)});
+    q_.push_back({j, std::move(hs), jr});
     cv_.notify_all();
     return "";
   }
@@ -294,7 +345,7 @@ class Closer {
   double busy_s() const { return busy_s_; }
 
  private:
-  struct Item { Job job; std::vector<bp_handle*> hs; };
+  struct Item { Job job; std::vector<bp_handle*> hs; JobRows rows; };
   void Run() {
     for (;;) {
       Item it;
@@ -310,7 +361,7 @@ class Closer {
         std::unique_lock<std::mutex> lk(mu_);
         e = err_;
       }
-      if (e.empty()) e = drv_->FinishJob(it.job, it.hs);
+      if (e.empty()) e = drv_->FinishJob(it.job, it.hs, it.rows);
       else for (bp_handle* h : it.hs) if (h) bp_destroy(h);  // after an error: only free
       busy_s_ += Now() - t0;
       std::unique_lock<std::mutex> lk(mu_);
@@ -432,6 +483,8 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
 
   Driver drv(opts, hd, bed, tsv_format ? 1 : 0);
   drv.per_read = per_read;
+  drv.device_text = (fmt == kBsTsv || fmt == kBsTsvBgz) && !per_read && !getenv("BIO_PILEUP_HOST_TEXT");
+  drv.ref_seqs = &ref_seqs;
   const int n_stream = opts.PerStrand ? 2 : 1;
   drv.streams.resize((size_t)n_stream);
   for (int s = 0; s < n_stream; s++) {
@@ -491,7 +544,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     std::string e = drv.Submit(&pend[0]);
     st.submit_s += Now() - t0;
     t0 = Now();
-    if (e.empty()) e = closer.Push(jobs[ji], drv.TakeHandles());
+    if (e.empty()) e = closer.Push(jobs[ji], drv.TakeHandles(), drv.open_rows);
     st.close_wait_s += Now() - t0;
     st.jobs++;
     open = false;

@@ -34,6 +34,8 @@ void launch_rows_add(uint32_t* rows, const uint32_t* src, int64_t n_u32, hipStre
 int window_size();
 void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned long long* tile_sum, hipStream_t s);
 void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s);
+void launch_text(const TextParams& T, hipStream_t s);
+void launch_text_write(const TextParams& T, hipStream_t s);
 }  // namespace bp
 
 using namespace bp;
@@ -108,8 +110,12 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_tile_lo, d_pr_feat, d_items, d_coarse;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_tile_lo, d_pr_feat, d_seq8, d_refname, d_txt_len, d_txt_tile, d_txt_out, d_items, d_coarse;
   bool per_read_valid = false;
+  int32_t seq_ref = -1, seq_start = 0;  // bp_set_ref_seq8
+  int64_t seq_len = 0;
+  bool iv_ref_uploaded = false;
+  size_t txt_len = 0;  // bytes of the text bp_render_basestrand_tsv left on the device
   uint64_t n_feat = 0;
   std::vector<unsigned long long> pr_tile_base;  // per 1024 lists: entries before them
   Staging stage[2];
@@ -985,6 +991,100 @@ int bp_per_read_features(bp_handle* h, uint64_t first, uint64_t n, bp_per_read* 
   return BP_OK;
 }
 
+int bp_set_ref_seq8(bp_handle* h, int32_t ref_id, int32_t start, const uint8_t* seq8, int64_t n) {
+  if (!h || (!seq8 && n)) return fail(h, BP_EINVAL, "bp_set_ref_seq8: null argument");
+  if (ref_id < 0 || (size_t)ref_id >= h->ref_len.size() || start < 0 || n < 0)
+    return fail(h, BP_EINVAL, "bp_set_ref_seq8: reference %d, start %d, %lld bases", ref_id, start, (long long)n);
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = ensure(h, h->d_seq8, (size_t)n + 256, 0)) return rc;
+  if (n) HIP_TRY(h, hipMemcpyAsync(h->d_seq8.p, seq8, (size_t)n, hipMemcpyHostToDevice, h->stream));
+  const std::string& nm = (size_t)ref_id < h->ref_name.size() ? h->ref_name[(size_t)ref_id] : std::string();
+  if (int rc = ensure(h, h->d_refname, nm.size() + 256, 0)) return rc;
+  if (!nm.empty()) HIP_TRY(h, hipMemcpyAsync(h->d_refname.p, nm.data(), nm.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller's buffers are free again
+  h->seq_ref = ref_id;
+  h->seq_start = start;
+  h->seq_len = n;
+  return BP_OK;
+}
+
+int64_t bp_render_basestrand_tsv_bound(const bp_handle* h, int64_t n_rows) {
+  if (!h || h->seq_ref < 0 || n_rows < 0) return -1;
+  const size_t nm = (size_t)h->seq_ref < h->ref_name.size() ? h->ref_name[(size_t)h->seq_ref].size() : 0;
+  return n_rows * (int64_t)(nm + 1 + 11 + 2 + 8 * 11);
+}
+
+int bp_render_basestrand_tsv(bp_handle* h, int64_t first, int64_t n, char* out, size_t cap, size_t* len) {
+  if (!h || !len) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: null argument");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: no computed rows (call bp_finish)");
+  if (h->seq_ref < 0) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: call bp_set_ref_seq8 first");
+  if (first < 0 || n < 0 || first + n > h->n_rows)
+    return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: rows [%lld,%lld) of %lld", (long long)first,
+                (long long)(first + n), (long long)h->n_rows);
+  *len = 0;
+  h->txt_len = 0;
+  if (n == 0) return BP_OK;
+  if (out && (int64_t)cap < bp_render_basestrand_tsv_bound(h, n))
+    return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: buffer of %llu bytes for %lld rows (see bp_render_basestrand_tsv_bound)",
+                (unsigned long long)cap, (long long)n);
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t n_iv = h->iv_ref.size();
+  if (!h->iv_ref_uploaded) {
+    if (int rc = ensure(h, h->d_iv_ref, n_iv * 4 + 256, 0)) return rc;
+    if (n_iv) HIP_TRY(h, hipMemcpyAsync(h->d_iv_ref.p, h->iv_ref.data(), n_iv * 4, hipMemcpyHostToDevice, h->stream));
+    h->iv_ref_uploaded = true;
+  }
+  const int64_t n_tiles = (n + 1023) / 1024;
+  if (int rc = ensure(h, h->d_txt_len, (size_t)n * 4 + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_txt_tile, (size_t)(n_tiles + 1) * 8 + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_txt_out, (size_t)bp_render_basestrand_tsv_bound(h, n) + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4, h->stream));
+  TextParams T{};
+  T.rows = (const uint32_t*)h->d_rows.p;
+  T.iv_row = (const int64_t*)h->d_iv_row.p;
+  T.iv_start = (const int32_t*)h->d_iv_start.p;
+  T.iv_ref = (const int32_t*)h->d_iv_ref.p;
+  T.seq8 = (const uint8_t*)h->d_seq8.p;
+  T.name = (const char*)h->d_refname.p;
+  T.len = (uint32_t*)h->d_txt_len.p;
+  T.tile = (unsigned long long*)h->d_txt_tile.p;
+  T.out = (char*)h->d_txt_out.p;
+  T.bad = (int32_t*)h->d_err.p;
+  T.first = first;
+  T.n = n;
+  T.seq_len = h->seq_len;
+  T.n_iv = (int32_t)n_iv;
+  T.seq_ref = h->seq_ref;
+  T.seq_start = h->seq_start;
+  T.name_len = (int32_t)((size_t)h->seq_ref < h->ref_name.size() ? h->ref_name[(size_t)h->seq_ref].size() : 0);
+  launch_text(T, h->stream);
+  launch_text_write(T, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  unsigned long long total = 0;
+  int32_t bad = 0;
+  HIP_TRY(h, hipMemcpyAsync(&total, T.tile + n_tiles, 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&bad, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (bad) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: a row of [%lld,%lld) has no reference base (bp_set_ref_seq8 covers reference %d, positions [%d,%lld))",
+                       (long long)first, (long long)(first + n), h->seq_ref, h->seq_start, (long long)h->seq_start + (long long)h->seq_len);
+  if ((int64_t)total > bp_render_basestrand_tsv_bound(h, n)) return fail(h, BP_EDEVICE, "bp_render_basestrand_tsv: text of %llu bytes", total);
+  h->txt_len = (size_t)total;
+  *len = (size_t)total;
+  if (out) HIP_TRY(h, hipMemcpy(out, h->d_txt_out.p, (size_t)total, hipMemcpyDeviceToHost));
+  return BP_OK;
+}
+
+int bp_render_fetch(bp_handle* h, char* out, size_t cap) {
+  if (!h || (!out && h->txt_len)) return fail(h, BP_EINVAL, "bp_render_fetch: null argument");
+  if (cap < h->txt_len) return fail(h, BP_EINVAL, "bp_render_fetch: buffer of %llu bytes for %llu of text",
+                                    (unsigned long long)cap, (unsigned long long)h->txt_len);
+  if (h->txt_len == 0) return BP_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy(out, h->d_txt_out.p, h->txt_len, hipMemcpyDeviceToHost));
+  return BP_OK;
+}
+
 int bp_get_timing(const bp_handle* h, bp_timing* out) {
   if (!h || !out) return BP_EINVAL;
   *out = h->timing;
@@ -1009,7 +1109,7 @@ void bp_destroy(bp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_tile_lo, &h->d_pr_feat, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_tile_lo, &h->d_pr_feat, &h->d_seq8, &h->d_refname, &h->d_txt_len, &h->d_txt_tile, &h->d_txt_out, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {

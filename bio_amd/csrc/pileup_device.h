@@ -141,4 +141,22 @@ struct PerReadParams {
   int32_t n_iv;
 };
 
+// Output conversion on the device: rows -> basestrand-tsv text (ConvertPileupRowsToBasestrandTSV,
+// pileup/snp/output.go:376-453, the column set without per-read lists).
+struct TextParams {
+  const uint32_t* rows;
+  const int64_t* iv_row;     // [n_iv + 1]
+  const int32_t* iv_start;
+  const int32_t* iv_ref;
+  const uint8_t* seq8;       // Seq8 bases of reference seq_ref, positions [seq_start, seq_start + seq_len)
+  const char* name;          // that reference's name
+  uint32_t* len;             // [n] text length of each row, then its offset inside its tile of 1024 rows
+  unsigned long long* tile;  // [ceil(n / 1024) + 1] tile totals, then tile offsets and the total
+  char* out;
+  int32_t* bad;              // set when a row has no reference base
+  int64_t first, n;
+  int64_t seq_len;
+  int32_t n_iv, seq_ref, seq_start, name_len;
+};
+
 }  // namespace bp

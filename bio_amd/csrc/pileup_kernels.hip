@@ -1617,6 +1617,127 @@ void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s) {
   else hipLaunchKernelGGL((per_read_kernel<false>), grid, block, lds, s, P, Q);
 }
 
+// ---------------------------------------------------------------- rows -> text
+// ConvertPileupRowsToBasestrandTSV (output.go:376-453) for the column set without per-read
+// lists: "<chrom>\t<pos+1>\t<REF>\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-\n" per BED position.  The
+// reference does this serially on the host at the end of the run ("up to ~35%" of its wall
+// clock, output.go:143-148); here the text is laid out by a scan of the line lengths and
+// written by one thread per row, and only text crosses PCIe (34 bytes per row instead of 44).
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+  return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u
+       : v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ char* put_dec(char* p, uint32_t v, char term) {
+  const uint32_t d = dec_digits(v);
+  for (uint32_t k = d; k-- > 0;) { p[k] = (char)('0' + v % 10u); v /= 10u; }
+  p[d] = term;
+  return p + d + 1;
+}
+// row -> (reference, position)
+__device__ __forceinline__ void text_row_pos(const TextParams& T, int64_t R, int32_t& ref, int32_t& pos) {
+  int32_t a = 0, b = T.n_iv;  // last interval with iv_row <= R
+  while (b - a > 1) {
+    const int32_t m = (a + b) >> 1;
+    if (T.iv_row[m] <= R) a = m; else b = m;
+  }
+  ref = T.iv_ref[a];
+  pos = T.iv_start[a] + (int32_t)(R - T.iv_row[a]);
+}
+
+// line lengths, scanned inside tiles of 1024 rows
+__global__ __launch_bounds__(256) void text_len_kernel(TextParams T) {
+  __shared__ uint32_t sh[256];
+  const int64_t base = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+  uint32_t v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    v[k] = 0;
+    const int64_t i = base + k;
+    if (i < T.n) {
+      int32_t ref, pos;
+      text_row_pos(T, T.first + i, ref, pos);
+      if (ref != T.seq_ref || pos < T.seq_start || (int64_t)pos - T.seq_start >= T.seq_len) *T.bad = 1;
+      const uint32_t* r = T.rows + (T.first + i) * 11;
+      uint32_t L = (uint32_t)T.name_len + 1u + dec_digits((uint32_t)pos + 1u) + 1u + 2u;
+#pragma unroll
+      for (int c = 1; c <= 8; c++) L += dec_digits(r[c]) + 1u;
+      v[k] = L;
+    }
+    s += v[k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = sh[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k < T.n) T.len[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 255) T.tile[blockIdx.x] = sh[255];
+}
+
+// exclusive scan of the tile totals by one workgroup; tile[n_tiles] = length of the whole text
+__global__ __launch_bounds__(1024) void text_tile_scan_kernel(unsigned long long* tile, int64_t n_tiles) {
+  __shared__ unsigned long long sh[1024];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t b = 0; b < n_tiles; b += 1024) {
+    const int64_t i = b + threadIdx.x;
+    const unsigned long long v = i < n_tiles ? tile[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const unsigned long long t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n_tiles) tile[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tile[n_tiles] = carry;
+}
+
+__global__ void text_write_kernel(TextParams T) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T.n) return;
+  int32_t ref, pos;
+  text_row_pos(T, T.first + i, ref, pos);
+  if (ref != T.seq_ref || pos < T.seq_start || (int64_t)pos - T.seq_start >= T.seq_len) return;
+  char* p = T.out + T.tile[i >> 10] + T.len[i];
+  for (int32_t k = 0; k < T.name_len; k++) p[k] = T.name[k];
+  p += T.name_len;
+  *p++ = '\t';
+  p = put_dec(p, (uint32_t)pos + 1u, '\t');
+  // Seq8ToASCIITable (pileup/common.go:72)
+  const char kSeq8[17] = "=ACMGRSVTWYHKDBN";
+  *p++ = kSeq8[T.seq8[pos - T.seq_start] & 15];
+  *p++ = '\t';
+  const uint32_t* r = T.rows + (T.first + i) * 11;
+#pragma unroll
+  for (int c = 1; c <= 8; c++) p = put_dec(p, r[c], c == 8 ? '\n' : '\t');
+}
+
+void launch_text(const TextParams& T, hipStream_t s) {
+  if (T.n == 0) return;
+  const int64_t n_tiles = (T.n + 1023) / 1024;
+  hipLaunchKernelGGL(text_len_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, T);
+  hipLaunchKernelGGL(text_tile_scan_kernel, dim3(1), dim3(1024), 0, s, T.tile, n_tiles);
+}
+void launch_text_write(const TextParams& T, hipStream_t s) {
+  if (T.n == 0) return;
+  hipLaunchKernelGGL(text_write_kernel, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, s, T);
+}
+
 // ---- launch wrappers (called from pileup_api.hip)
 void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s) {
   if (P.n_windows == 0) return;

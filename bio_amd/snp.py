@@ -136,6 +136,21 @@ class PileupJob:
         self._check(self.lib.bp_per_read_features(self.h, lo, hi - lo, feats.ctypes.data_as(C.c_void_p)))
         return off - off[0], feats
 
+    def set_ref_seq8(self, ref_id, start, seq8):
+        """Seq8 bases (numpy uint8) of positions [start, start+len) of one reference, for render_text"""
+        a = np.ascontiguousarray(seq8, np.uint8)
+        self._check(self.lib.bp_set_ref_seq8(self.h, ref_id, start, a.ctypes.data, len(a)))
+
+    def render_text(self, first=0, n=None):
+        """basestrand-tsv lines of rows [first, first+n), rendered on the device (bytes)"""
+        if n is None:
+            n = self.num_rows - first
+        cap = int(self.lib.bp_render_basestrand_tsv_bound(self.h, n))
+        buf = C.create_string_buffer(max(cap, 1))
+        ln = C.c_size_t(0)
+        self._check(self.lib.bp_render_basestrand_tsv(self.h, first, n, buf, cap, C.byref(ln)))
+        return buf.raw[:ln.value]
+
     def rows_export(self, first, n, dst_device_ptr):
         """rows [first, first+n) -> n*11 uint32 at a device address (boundary exchange)"""
         self._check(self.lib.bp_rows_export(self.h, first, n, dst_device_ptr))

@@ -189,6 +189,21 @@ int bp_per_read_offsets(bp_handle* h, int64_t first_row, int64_t n_rows, uint64_
 /* Copies entries [first, first+n) to host. */
 int bp_per_read_features(bp_handle* h, uint64_t first, uint64_t n, bp_per_read* out);
 
+/* Output conversion on the device: ConvertPileupRowsToBasestrandTSV (pileup/snp/output.go:376-453,
+ * writeChromPosRef :36-40) for the column set without per-read lists.  Rows [first, first+n)
+ * become "<chrom>\t<pos+1>\t<REF>\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-\n" lines, rendered on the
+ * device and copied to `out` (host memory of at least bp_render_basestrand_tsv_bound(h, n)
+ * bytes); *len = bytes written.  REF comes from the Seq8 bases (encoding/fasta/fasta.go:50-62)
+ * given by bp_set_ref_seq8 for ONE reference, positions [start, start+n): every rendered row must
+ * lie there (the reference indexes refSeqs[refID][pos], output.go:158).  <chrom> is the
+ * ref_name given to bp_create.  With out = NULL the text stays on the device, *len says how long
+ * it is, and bp_render_fetch copies it to a buffer of that size (so the caller can size its
+ * buffer exactly). */
+int bp_set_ref_seq8(bp_handle* h, int32_t ref_id, int32_t start, const uint8_t* seq8, int64_t n);
+int64_t bp_render_basestrand_tsv_bound(const bp_handle* h, int64_t n_rows);
+int bp_render_basestrand_tsv(bp_handle* h, int64_t first, int64_t n, char* out, size_t cap, size_t* len);
+int bp_render_fetch(bp_handle* h, char* out, size_t cap);
+
 int bp_get_timing(const bp_handle* h, bp_timing* out);
 
 /* Algorithmic bytes of the resident job per SURVEY.md section 8(d):

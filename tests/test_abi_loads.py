@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_header_symbols_exported():
     hdr = open(os.path.join(ROOT, "include", "bio_pileup.h")).read()
-    declared = set(re.findall(r"\b(bp_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(bp_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
     lib = _abi.load()
     for name in declared:

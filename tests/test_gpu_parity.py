@@ -471,3 +471,50 @@ def test_full_size_chr1_30x_properties():
                 n = min(step, L - r0)
                 assert (ja.rows(r0, n)[2] == job.rows(r0, n)[2]).all(), r0
     sb.close()
+
+
+def test_rows_to_text_on_device():
+    """bp_render_basestrand_tsv against the same lines formatted here from bp_rows
+    (ConvertPileupRowsToBasestrandTSV, output.go:376-453: chrom, 1-based pos, REF from
+    Seq8ToASCIITable, the eight per-strand counts), over several BED intervals of two
+    references, in sub-ranges that straddle the 1,024-row tiles of the length scan."""
+    rng = random.Random(77)
+    ref_lens = [6000, 3500]
+    names = ["chr2_subset", "chrUn_KI270442v1"]
+    recs = []
+    for r, L in enumerate(ref_lens):
+        part = random_records(rng, 500, ref_len=L, read_len=80)
+        for x in part:
+            x["mate_ref_id"] = r if x["mate_ref_id"] == x["ref_id"] else 1 - r
+            x["ref_id"] = r
+        recs += part
+    recs.sort(key=lambda x: (x["ref_id"], x["pos"]))
+    batch = R.from_records(recs)
+    bed = {0: [[10, 2500], [2600, 2601], [3000, 5990]], 1: [[0, 1200], [1500, 3400]]}
+    opts = O.make_opts(max_read_len=100, max_read_span=150, min_base_qual=12)
+    ascii_of = "=ACMGRSVTWYHKDBN"
+    with snp.PileupJob(opts, ref_lens, names) as job:
+        job.set_bed(bed)
+        job.submit(batch)
+        job.finish()
+        ref, pos, vals = job.rows()
+        assert vals[:, 0].max() > 10
+        n0 = int((ref == 0).sum())
+        for r, (lo, hi) in enumerate([(0, n0), (n0, len(pos))]):
+            seq = np.array([rng.choice([1, 2, 4, 8, 15, 5, 0]) for _ in range(ref_lens[r])], np.uint8)
+            start = int(pos[lo])
+            job.set_ref_seq8(r, start, seq[start:int(pos[hi - 1]) + 1])
+            want = b"".join(
+                ("%s\t%d\t%s\t%s\n" % (names[r], pos[i] + 1, ascii_of[seq[pos[i]] & 15],
+                                       "\t".join(str(int(c)) for c in vals[i, 1:9]))).encode()
+                for i in range(lo, hi))
+            assert job.render_text(lo, hi - lo) == want
+            # a sub-range that starts and ends inside tiles of the scan
+            a, b = lo + 700, min(hi, lo + 2900)
+            got = job.render_text(a, b - a)
+            assert got == b"".join(want.splitlines(keepends=True)[a - lo:b - lo])
+            assert job.render_text(lo, 0) == b""
+            # rows of the other reference have no base to show
+            other = (n0, 5) if r == 0 else (0, 5)
+            with pytest.raises(snp.PileupError, match="no reference base"):
+                job.render_text(*other)

@@ -67,7 +67,7 @@ EXPORTS = [
     "bp_num_rows", "bp_rows", "bp_rows_device", "bp_rows_export", "bp_rows_accumulate", "bp_column_sums", "bp_get_timing",
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
-    "bp_set_ref_seq8", "bp_render_basestrand_tsv_bound", "bp_render_basestrand_tsv", "bp_render_fetch",
+    "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch",
 ]
 
 HOST_EXPORTS = [
@@ -152,10 +152,11 @@ def load():
     lib.bp_destroy.restype = None
     lib.bp_set_ref_seq8.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
     lib.bp_set_ref_seq8.restype = C.c_int
-    lib.bp_render_basestrand_tsv_bound.argtypes = [H, C.c_int64]
-    lib.bp_render_basestrand_tsv_bound.restype = C.c_int64
-    lib.bp_render_basestrand_tsv.argtypes = [H, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.bp_render_basestrand_tsv.restype = C.c_int
+    lib.bp_render_text_bound.argtypes = [H, C.c_int32, C.c_int64]
+    lib.bp_render_text_bound.restype = C.c_int64
+    lib.bp_render_text.argtypes = [H, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_size_t)]
+    lib.bp_render_text.restype = C.c_int
     lib.bp_render_fetch.argtypes = [H, C.c_void_p, C.c_size_t]
     lib.bp_render_fetch.restype = C.c_int
     lib.bp_per_read_build.argtypes = [H]

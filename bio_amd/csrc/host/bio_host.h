@@ -190,10 +190,15 @@ class RowWriter {
   // points at entry off[0]); both NULL unless a per-read column set was requested.
   virtual std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                             const uint64_t* off, const bp_per_read* feats) = 0;
-  // Lines already rendered (on the device, bp_render_basestrand_tsv), appended as they are.
-  // A string to render into: one the sink has finished with (capacity kept, no fresh pages) if any.
-  virtual std::string SpareText() { return std::string(); }
-  virtual std::string WriteText(std::string&& text) { (void)text; return "pileup output: this format takes rows, not text"; }
+  // Lines already rendered (on the device, bp_render_text), appended as they are to output file
+  // `which` of the format (basestrand-tsv: 0; tsv: 0 = .ref.tsv, 1 = .alt.tsv).
+  // SpareText: a string to render into, one the sink has finished with (capacity kept, no fresh
+  // pages) if there is one.
+  virtual std::string SpareText(int which) { (void)which; return std::string(); }
+  virtual std::string WriteText(int which, std::string&& text) {
+    (void)which; (void)text;
+    return "pileup output: this format takes rows, not text";
+  }
   virtual std::string Close() = 0;
 };
 // ConvertPileupRowsToTSV (output.go:42-300): <prefix>.ref.tsv[.gz] + <prefix>.alt.tsv[.gz]

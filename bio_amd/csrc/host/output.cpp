@@ -322,6 +322,11 @@ class TsvWriter : public RowWriter {
       w.EndCsv();
     }
   }
+  std::string SpareText(int which) override { return which == 0 ? ref_.Spare() : alt_.Spare(); }
+  std::string WriteText(int which, std::string&& text) override {
+    if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
+    return which == 0 ? ref_.Append(std::move(text)) : alt_.Append(std::move(text));
+  }
   std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                     const uint64_t* off, const bp_per_read* feats) override {
     const bool per_read = (cols_ & kPerReadMask) != 0;
@@ -443,8 +448,8 @@ class BasestrandTsvWriter : public RowWriter {
     }
   }
   static void AppendUint(std::string& s, uint32_t v) { s += std::to_string(v); s.push_back(','); }
-  std::string SpareText() override { return w_.Spare(); }
-  std::string WriteText(std::string&& text) override {
+  std::string SpareText(int) override { return w_.Spare(); }
+  std::string WriteText(int, std::string&& text) override {
     if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
     return w_.Append(std::move(text));
   }

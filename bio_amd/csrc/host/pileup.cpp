@@ -94,7 +94,7 @@ struct Job {
 // What closing a job needs besides its handles.
 struct JobRows {
   int64_t row_lo = 0, row_hi = 0;  // the handle's rows [row_lo, row_hi) lie in the job's own range
-  bool device_text = false;        // the device renders the lines (bp_render_basestrand_tsv)
+  bool device_text = false;        // the device renders the lines (bp_render_text)
 };
 
 struct Stream {  // one output stream = one strand pass (pileup.go:1118-1128)
@@ -137,6 +137,8 @@ class Driver {
   bool per_read = false;  // a per-read column set is requested (pCtx.perReadNeeded)
   // basestrand-tsv without per-read columns: the rows become text on the device
   bool device_text = false;
+  bool text_tsv = false;   // ... of the tsv format (two files) rather than basestrand-tsv
+  int32_t text_cols = 0;   // its -cols bits
   const std::vector<const std::string*>* ref_seqs = nullptr;
   JobRows open_rows;  // of the open job
 
@@ -254,13 +256,17 @@ class Driver {
       if (bp_finish(h) != BP_OK) return HandleErr(h);
       for (int64_t first = jr.row_lo; first < jr.row_hi; first += kRowChunk) {
         const int64_t m = std::min<int64_t>(kRowChunk, jr.row_hi - first);
-        size_t len = 0;
-        if (bp_render_basestrand_tsv(h, first, m, nullptr, 0, &len) != BP_OK) return HandleErr(h);
-        std::string text = streams[si].writer->SpareText();
-        text.resize(len);
-        if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
-        std::string err = streams[si].writer->WriteText(std::move(text));
-        if (!err.empty()) return err;
+        // basestrand-tsv: one file; tsv: the .ref.tsv and the .alt.tsv lines of the same rows
+        for (int which = 0; which < (text_tsv ? 2 : 1); which++) {
+          const int32_t kind = text_tsv ? (which == 0 ? BP_TEXT_TSV_REF : BP_TEXT_TSV_ALT) : BP_TEXT_BASESTRAND;
+          size_t len = 0;
+          if (bp_render_text(h, kind, text_cols, first, m, nullptr, 0, &len) != BP_OK) return HandleErr(h);
+          std::string text = streams[si].writer->SpareText(which);
+          text.resize(len);
+          if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
+          std::string err = streams[si].writer->WriteText(which, std::move(text));
+          if (!err.empty()) return err;
+        }
       }
     }
     return "";
@@ -483,7 +489,11 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
 
   Driver drv(opts, hd, bed, tsv_format ? 1 : 0);
   drv.per_read = per_read;
-  drv.device_text = (fmt == kBsTsv || fmt == kBsTsvBgz) && !per_read && !getenv("BIO_PILEUP_HOST_TEXT");
+  // without per-read columns the rows become text on the device (BIO_PILEUP_HOST_TEXT=1 keeps
+  // the host renderer, for tests that compare the two)
+  drv.device_text = !per_read && !getenv("BIO_PILEUP_HOST_TEXT");
+  drv.text_tsv = tsv_format;
+  drv.text_cols = cols & (kColDpRef | kColDpAlt | kColHighQ | kColLowQ);
   drv.ref_seqs = &ref_seqs;
   const int n_stream = opts.PerStrand ? 2 : 1;
   drv.streams.resize((size_t)n_stream);

@@ -1008,24 +1008,31 @@ int bp_set_ref_seq8(bp_handle* h, int32_t ref_id, int32_t start, const uint8_t* 
   return BP_OK;
 }
 
-int64_t bp_render_basestrand_tsv_bound(const bp_handle* h, int64_t n_rows) {
-  if (!h || h->seq_ref < 0 || n_rows < 0) return -1;
+int64_t bp_render_text_bound(const bp_handle* h, int32_t kind, int64_t n_rows) {
+  if (!h || h->seq_ref < 0 || n_rows < 0 || kind < 0 || kind > 2) return -1;
   const size_t nm = (size_t)h->seq_ref < h->ref_name.size() ? h->ref_name[(size_t)h->seq_ref].size() : 0;
-  return n_rows * (int64_t)(nm + 1 + 11 + 2 + 8 * 11);
+  const size_t head = nm + 1 + 11 + 2;
+  if (kind == BP_TEXT_BASESTRAND) return n_rows * (int64_t)(head + 8 * 11);
+  if (kind == BP_TEXT_TSV_REF) return n_rows * (int64_t)(head + 11 + 11 + 2);
+  return n_rows * (int64_t)(4 * (head + 2 + 11 + 11 + 2));
 }
 
-int bp_render_basestrand_tsv(bp_handle* h, int64_t first, int64_t n, char* out, size_t cap, size_t* len) {
-  if (!h || !len) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: null argument");
-  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: no computed rows (call bp_finish)");
-  if (h->seq_ref < 0) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: call bp_set_ref_seq8 first");
+int bp_render_text(bp_handle* h, int32_t kind, int32_t cols, int64_t first, int64_t n, char* out, size_t cap,
+                   size_t* len) {
+  if (!h || !len) return fail(h, BP_EINVAL, "bp_render_text: null argument");
+  if (kind < 0 || kind > 2) return fail(h, BP_EINVAL, "bp_render_text: kind %d", kind);
+  if (cols & ~(BP_COL_DPREF | BP_COL_DPALT | BP_COL_HIGHQ | BP_COL_LOWQ))
+    return fail(h, BP_EINVAL, "bp_render_text: per-read columns are not rendered on the device");
+  if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_render_text: no computed rows (call bp_finish)");
+  if (h->seq_ref < 0) return fail(h, BP_EINVAL, "bp_render_text: call bp_set_ref_seq8 first");
   if (first < 0 || n < 0 || first + n > h->n_rows)
-    return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: rows [%lld,%lld) of %lld", (long long)first,
+    return fail(h, BP_EINVAL, "bp_render_text: rows [%lld,%lld) of %lld", (long long)first,
                 (long long)(first + n), (long long)h->n_rows);
   *len = 0;
   h->txt_len = 0;
   if (n == 0) return BP_OK;
-  if (out && (int64_t)cap < bp_render_basestrand_tsv_bound(h, n))
-    return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: buffer of %llu bytes for %lld rows (see bp_render_basestrand_tsv_bound)",
+  if (out && (int64_t)cap < bp_render_text_bound(h, kind, n))
+    return fail(h, BP_EINVAL, "bp_render_text: buffer of %llu bytes for %lld rows (see bp_render_text_bound)",
                 (unsigned long long)cap, (long long)n);
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t n_iv = h->iv_ref.size();
@@ -1037,7 +1044,7 @@ int bp_render_basestrand_tsv(bp_handle* h, int64_t first, int64_t n, char* out, 
   const int64_t n_tiles = (n + 1023) / 1024;
   if (int rc = ensure(h, h->d_txt_len, (size_t)n * 4 + 256, 0)) return rc;
   if (int rc = ensure(h, h->d_txt_tile, (size_t)(n_tiles + 1) * 8 + 256, 0)) return rc;
-  if (int rc = ensure(h, h->d_txt_out, (size_t)bp_render_basestrand_tsv_bound(h, n) + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_txt_out, (size_t)bp_render_text_bound(h, kind, n) + 256, 0)) return rc;
   if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
   HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4, h->stream));
   TextParams T{};
@@ -1058,6 +1065,8 @@ int bp_render_basestrand_tsv(bp_handle* h, int64_t first, int64_t n, char* out, 
   T.seq_ref = h->seq_ref;
   T.seq_start = h->seq_start;
   T.name_len = (int32_t)((size_t)h->seq_ref < h->ref_name.size() ? h->ref_name[(size_t)h->seq_ref].size() : 0);
+  T.kind = kind;
+  T.cols = cols;
   launch_text(T, h->stream);
   launch_text_write(T, h->stream);
   HIP_TRY(h, hipGetLastError());
@@ -1066,9 +1075,9 @@ int bp_render_basestrand_tsv(bp_handle* h, int64_t first, int64_t n, char* out, 
   HIP_TRY(h, hipMemcpyAsync(&total, T.tile + n_tiles, 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(&bad, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (bad) return fail(h, BP_EINVAL, "bp_render_basestrand_tsv: a row of [%lld,%lld) has no reference base (bp_set_ref_seq8 covers reference %d, positions [%d,%lld))",
+  if (bad) return fail(h, BP_EINVAL, "bp_render_text: a row of [%lld,%lld) has no reference base (bp_set_ref_seq8 covers reference %d, positions [%d,%lld))",
                        (long long)first, (long long)(first + n), h->seq_ref, h->seq_start, (long long)h->seq_start + (long long)h->seq_len);
-  if ((int64_t)total > bp_render_basestrand_tsv_bound(h, n)) return fail(h, BP_EDEVICE, "bp_render_basestrand_tsv: text of %llu bytes", total);
+  if ((int64_t)total > bp_render_text_bound(h, kind, n)) return fail(h, BP_EDEVICE, "bp_render_text: text of %llu bytes", total);
   h->txt_len = (size_t)total;
   *len = (size_t)total;
   if (out) HIP_TRY(h, hipMemcpy(out, h->d_txt_out.p, (size_t)total, hipMemcpyDeviceToHost));

@@ -157,6 +157,7 @@ struct TextParams {
   int64_t first, n;
   int64_t seq_len;
   int32_t n_iv, seq_ref, seq_start, name_len;
+  int32_t kind, cols;        // BP_TEXT_* and the -cols bit set (bio_pileup.h)
 };
 
 }  // namespace bp

@@ -1644,6 +1644,81 @@ __device__ __forceinline__ void text_row_pos(const TextParams& T, int64_t R, int
   pos = T.iv_start[a] + (int32_t)(R - T.iv_row[a]);
 }
 
+// The lines of one row.  kind 0: basestrand-tsv (output.go:437-453).  kind 1 / 2: the .ref.tsv /
+// .alt.tsv files of the tsv format (output.go:149-276) with the columns of T.cols that are not
+// per-read lists: ref line = chrom, pos, REF, [DP], [ref_depth_tier1 = Counts[ref][+]+Counts[ref][-]],
+// [ref_depth_tier2 = 0]; one alt line per base A,C,G,T,N other than REF with a nonzero count =
+// chrom, pos, REF, ALT, [DP], [alt_depth_tier1], [alt_depth_tier2 = 0].
+enum { TEXT_COL_DPREF = 1, TEXT_COL_DPALT = 2, TEXT_COL_HIGHQ = 64, TEXT_COL_LOWQ = 128 };  // pileup.ParseCols bits (common.go:118-166)
+__device__ __forceinline__ uint32_t seq8_enum(uint32_t b8) {  // Seq8ToEnumTable (common.go:66)
+  return b8 == 1 ? 0u : b8 == 2 ? 1u : b8 == 4 ? 2u : b8 == 8 ? 3u : 4u;
+}
+__device__ __forceinline__ uint32_t text_row_len(const TextParams& T, int32_t pos, const uint32_t* r, uint32_t b8) {
+  const uint32_t head = (uint32_t)T.name_len + 1u + dec_digits((uint32_t)pos + 1u) + 1u + 2u;
+  if (T.kind == 0) {
+    uint32_t L = head;
+#pragma unroll
+    for (int c = 1; c <= 8; c++) L += dec_digits(r[c]) + 1u;
+    return L;
+  }
+  const uint32_t rb = seq8_enum(b8);
+  const uint32_t lowq = (T.cols & TEXT_COL_LOWQ) ? 2u : 0u;
+  if (T.kind == 1) {
+    uint32_t L = head + lowq;
+    if (T.cols & TEXT_COL_DPREF) L += dec_digits(r[0]) + 1u;
+    if (T.cols & TEXT_COL_HIGHQ) L += dec_digits(r[1 + 2 * rb] + r[2 + 2 * rb]) + 1u;
+    return L;
+  }
+  uint32_t L = 0;
+  for (uint32_t alt = 0; alt < 5; alt++) {
+    const uint32_t c = r[1 + 2 * alt] + r[2 + 2 * alt];
+    if (alt == rb || c == 0) continue;
+    L += head + 2u + lowq;
+    if (T.cols & TEXT_COL_DPALT) L += dec_digits(r[0]) + 1u;
+    if (T.cols & TEXT_COL_HIGHQ) L += dec_digits(c) + 1u;
+  }
+  return L;
+}
+__device__ __forceinline__ char* text_head(const TextParams& T, char* p, int32_t pos, uint32_t b8) {
+  for (int32_t k = 0; k < T.name_len; k++) p[k] = T.name[k];
+  p += T.name_len;
+  *p++ = '\t';
+  p = put_dec(p, (uint32_t)pos + 1u, '\t');
+  const char kSeq8[17] = "=ACMGRSVTWYHKDBN";  // Seq8ToASCIITable (pileup/common.go:72)
+  *p++ = kSeq8[b8];
+  *p++ = '\t';
+  return p;
+}
+__device__ __forceinline__ void text_row_write(const TextParams& T, char* p, int32_t pos, const uint32_t* r, uint32_t b8) {
+  if (T.kind == 0) {
+    p = text_head(T, p, pos, b8);
+#pragma unroll
+    for (int c = 1; c <= 8; c++) p = put_dec(p, r[c], c == 8 ? '\n' : '\t');
+    return;
+  }
+  const uint32_t rb = seq8_enum(b8);
+  if (T.kind == 1) {
+    p = text_head(T, p, pos, b8);
+    if (T.cols & TEXT_COL_DPREF) p = put_dec(p, r[0], '\t');
+    if (T.cols & TEXT_COL_HIGHQ) p = put_dec(p, r[1 + 2 * rb] + r[2 + 2 * rb], '\t');
+    if (T.cols & TEXT_COL_LOWQ) { *p++ = '0'; *p++ = '\t'; }
+    p[-1] = '\n';  // EndLine: the last tab becomes the newline
+    return;
+  }
+  const char kEnum[6] = "ACGTN";  // EnumToASCIITable (common.go:69)
+  for (uint32_t alt = 0; alt < 5; alt++) {
+    const uint32_t c = r[1 + 2 * alt] + r[2 + 2 * alt];
+    if (alt == rb || c == 0) continue;
+    p = text_head(T, p, pos, b8);
+    *p++ = kEnum[alt];
+    *p++ = '\t';
+    if (T.cols & TEXT_COL_DPALT) p = put_dec(p, r[0], '\t');
+    if (T.cols & TEXT_COL_HIGHQ) p = put_dec(p, c, '\t');
+    if (T.cols & TEXT_COL_LOWQ) { *p++ = '0'; *p++ = '\t'; }
+    p[-1] = '\n';
+  }
+}
+
 // line lengths, scanned inside tiles of 1024 rows
 __global__ __launch_bounds__(256) void text_len_kernel(TextParams T) {
   __shared__ uint32_t sh[256];
@@ -1657,11 +1732,7 @@ __global__ __launch_bounds__(256) void text_len_kernel(TextParams T) {
       int32_t ref, pos;
       text_row_pos(T, T.first + i, ref, pos);
       if (ref != T.seq_ref || pos < T.seq_start || (int64_t)pos - T.seq_start >= T.seq_len) *T.bad = 1;
-      const uint32_t* r = T.rows + (T.first + i) * 11;
-      uint32_t L = (uint32_t)T.name_len + 1u + dec_digits((uint32_t)pos + 1u) + 1u + 2u;
-#pragma unroll
-      for (int c = 1; c <= 8; c++) L += dec_digits(r[c]) + 1u;
-      v[k] = L;
+      else v[k] = text_row_len(T, pos, T.rows + (T.first + i) * 11, T.seq8[pos - T.seq_start] & 15u);
     }
     s += v[k];
   }
@@ -1713,18 +1784,8 @@ __global__ void text_write_kernel(TextParams T) {
   int32_t ref, pos;
   text_row_pos(T, T.first + i, ref, pos);
   if (ref != T.seq_ref || pos < T.seq_start || (int64_t)pos - T.seq_start >= T.seq_len) return;
-  char* p = T.out + T.tile[i >> 10] + T.len[i];
-  for (int32_t k = 0; k < T.name_len; k++) p[k] = T.name[k];
-  p += T.name_len;
-  *p++ = '\t';
-  p = put_dec(p, (uint32_t)pos + 1u, '\t');
-  // Seq8ToASCIITable (pileup/common.go:72)
-  const char kSeq8[17] = "=ACMGRSVTWYHKDBN";
-  *p++ = kSeq8[T.seq8[pos - T.seq_start] & 15];
-  *p++ = '\t';
-  const uint32_t* r = T.rows + (T.first + i) * 11;
-#pragma unroll
-  for (int c = 1; c <= 8; c++) p = put_dec(p, r[c], c == 8 ? '\n' : '\t');
+  text_row_write(T, T.out + T.tile[i >> 10] + T.len[i], pos, T.rows + (T.first + i) * 11,
+                 T.seq8[pos - T.seq_start] & 15u);
 }
 
 void launch_text(const TextParams& T, hipStream_t s) {

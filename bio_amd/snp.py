@@ -141,14 +141,16 @@ class PileupJob:
         a = np.ascontiguousarray(seq8, np.uint8)
         self._check(self.lib.bp_set_ref_seq8(self.h, ref_id, start, a.ctypes.data, len(a)))
 
-    def render_text(self, first=0, n=None):
-        """basestrand-tsv lines of rows [first, first+n), rendered on the device (bytes)"""
+    def render_text(self, first=0, n=None, kind=0, cols=0):
+        """Output lines of rows [first, first+n), rendered on the device (bytes).  kind: 0
+        basestrand-tsv, 1 .ref.tsv, 2 .alt.tsv; cols: the -cols bits (1 dpref, 2 dpalt, 64 highq,
+        128 lowq)."""
         if n is None:
             n = self.num_rows - first
-        cap = int(self.lib.bp_render_basestrand_tsv_bound(self.h, n))
+        cap = int(self.lib.bp_render_text_bound(self.h, kind, n))
         buf = C.create_string_buffer(max(cap, 1))
         ln = C.c_size_t(0)
-        self._check(self.lib.bp_render_basestrand_tsv(self.h, first, n, buf, cap, C.byref(ln)))
+        self._check(self.lib.bp_render_text(self.h, kind, cols, first, n, buf, cap, C.byref(ln)))
         return buf.raw[:ln.value]
 
     def rows_export(self, first, n, dst_device_ptr):

@@ -189,19 +189,27 @@ int bp_per_read_offsets(bp_handle* h, int64_t first_row, int64_t n_rows, uint64_
 /* Copies entries [first, first+n) to host. */
 int bp_per_read_features(bp_handle* h, uint64_t first, uint64_t n, bp_per_read* out);
 
-/* Output conversion on the device: ConvertPileupRowsToBasestrandTSV (pileup/snp/output.go:376-453,
- * writeChromPosRef :36-40) for the column set without per-read lists.  Rows [first, first+n)
- * become "<chrom>\t<pos+1>\t<REF>\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-\n" lines, rendered on the
- * device and copied to `out` (host memory of at least bp_render_basestrand_tsv_bound(h, n)
- * bytes); *len = bytes written.  REF comes from the Seq8 bases (encoding/fasta/fasta.go:50-62)
- * given by bp_set_ref_seq8 for ONE reference, positions [start, start+n): every rendered row must
- * lie there (the reference indexes refSeqs[refID][pos], output.go:158).  <chrom> is the
- * ref_name given to bp_create.  With out = NULL the text stays on the device, *len says how long
- * it is, and bp_render_fetch copies it to a buffer of that size (so the caller can size its
- * buffer exactly). */
+/* Output conversion on the device: ConvertPileupRowsToBasestrandTSV (pileup/snp/output.go:376-453)
+ * and ConvertPileupRowsToTSV (output.go:42-300, writeChromPosRef :36-40) for column sets without
+ * per-read lists.  Rows [first, first+n) become the lines of one output file:
+ *   BP_TEXT_BASESTRAND  "<chrom>\t<pos+1>\t<REF>\tA+\tA-\tC+\tC-\tG+\tG-\tT+\tT-\n"
+ *   BP_TEXT_TSV_REF     "<chrom>\t<pos+1>\t<REF>[\tDP][\tref_depth_tier1][\t0]\n"          (.ref.tsv)
+ *   BP_TEXT_TSV_ALT     one "<chrom>\t<pos+1>\t<REF>\t<ALT>[\tDP][\talt_depth_tier1][\t0]\n" per base
+ *                       A,C,G,T,N other than REF with a nonzero count                         (.alt.tsv)
+ * `cols` = the -cols bit set (pileup.ParseCols, pileup/common.go:118-166) restricted to the BP_COL_*
+ * below; it is ignored for BP_TEXT_BASESTRAND.  The lines are rendered on the device and copied
+ * to `out` (host memory of at least bp_render_text_bound(h, kind, n) bytes); *len = bytes
+ * written.  With out = NULL the text stays on the device, *len says how long it is, and
+ * bp_render_fetch copies it to a buffer of that size.  REF comes from the Seq8 bases
+ * (encoding/fasta/fasta.go:50-62) given by bp_set_ref_seq8 for ONE reference, positions
+ * [start, start+n): every rendered row must lie there (the reference indexes refSeqs[refID][pos],
+ * output.go:158).  <chrom> is the ref_name given to bp_create. */
+enum { BP_TEXT_BASESTRAND = 0, BP_TEXT_TSV_REF = 1, BP_TEXT_TSV_ALT = 2 };
+enum { BP_COL_DPREF = 1, BP_COL_DPALT = 2, BP_COL_HIGHQ = 64, BP_COL_LOWQ = 128 };
 int bp_set_ref_seq8(bp_handle* h, int32_t ref_id, int32_t start, const uint8_t* seq8, int64_t n);
-int64_t bp_render_basestrand_tsv_bound(const bp_handle* h, int64_t n_rows);
-int bp_render_basestrand_tsv(bp_handle* h, int64_t first, int64_t n, char* out, size_t cap, size_t* len);
+int64_t bp_render_text_bound(const bp_handle* h, int32_t kind, int64_t n_rows);
+int bp_render_text(bp_handle* h, int32_t kind, int32_t cols, int64_t first, int64_t n, char* out, size_t cap,
+                   size_t* len);
 int bp_render_fetch(bp_handle* h, char* out, size_t cap);
 
 int bp_get_timing(const bp_handle* h, bp_timing* out);

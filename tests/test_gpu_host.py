@@ -432,3 +432,21 @@ def test_per_read_column_sets(tmp_path, monkeypatch):
     monkeypatch.delenv("BIO_PILEUP_JOB_SPAN")
     with pytest.raises(PileupError, match="stitched per-read features not yet supported"):
         host.pileup(c.bam, c.fa, "tsv", out, Opts(BedPath=c.bed_path, Cols="quals", Stitch=True))
+
+
+def test_host_renderer_writes_the_same_files(tmp_path, monkeypatch):
+    """Without per-read columns the lines come from the device (bp_render_text); the host
+    renderer (kept for the per-read column sets, forced here with BIO_PILEUP_HOST_TEXT) must
+    write the same bytes."""
+    c = Case(tmp_path, seed=21)
+    o = Opts(BedPath=c.bed_path, Mapq=20, MinBaseQual=15, Cols="dpref,dpalt,highq,lowq")
+    for fmt, files in (("tsv", ["ref.tsv", "alt.tsv"]), ("basestrand-tsv", ["basestrand.tsv"])):
+        monkeypatch.delenv("BIO_PILEUP_HOST_TEXT", raising=False)
+        host.pileup(c.bam, c.fa, fmt, str(tmp_path / "dev"), Opts(BedPath=c.bed_path, Mapq=20, MinBaseQual=15,
+                                                                  Cols=o.Cols if fmt == "tsv" else ""))
+        monkeypatch.setenv("BIO_PILEUP_HOST_TEXT", "1")
+        host.pileup(c.bam, c.fa, fmt, str(tmp_path / "cpu"), Opts(BedPath=c.bed_path, Mapq=20, MinBaseQual=15,
+                                                                  Cols=o.Cols if fmt == "tsv" else ""))
+        for f in files:
+            a, b = c.read("dev." + f), c.read("cpu." + f)
+            assert a == b and a.count("\n") > 100, f

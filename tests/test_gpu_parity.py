@@ -474,9 +474,10 @@ def test_full_size_chr1_30x_properties():
 
 
 def test_rows_to_text_on_device():
-    """bp_render_basestrand_tsv against the same lines formatted here from bp_rows
+    """bp_render_text against the same lines formatted here from bp_rows: basestrand-tsv
     (ConvertPileupRowsToBasestrandTSV, output.go:376-453: chrom, 1-based pos, REF from
-    Seq8ToASCIITable, the eight per-strand counts), over several BED intervals of two
+    Seq8ToASCIITable, the eight per-strand counts) and the .ref.tsv / .alt.tsv files of the tsv
+    format (output.go:149-276) under several -cols sets, over several BED intervals of two
     references, in sub-ranges that straddle the 1,024-row tiles of the length scan."""
     rng = random.Random(77)
     ref_lens = [6000, 3500]
@@ -492,7 +493,28 @@ def test_rows_to_text_on_device():
     batch = R.from_records(recs)
     bed = {0: [[10, 2500], [2600, 2601], [3000, 5990]], 1: [[0, 1200], [1500, 3400]]}
     opts = O.make_opts(max_read_len=100, max_read_span=150, min_base_qual=12)
-    ascii_of = "=ACMGRSVTWYHKDBN"
+    ascii_of, enum_of = "=ACMGRSVTWYHKDBN", {1: 0, 2: 1, 4: 2, 8: 3}
+
+    def lines(kind, cols, name, p, b8, v):
+        head = "%s\t%d\t%s" % (name, p + 1, ascii_of[b8])
+        if kind == 0:
+            return [head + "\t" + "\t".join(str(int(c)) for c in v[1:9]) + "\n"]
+        rb = enum_of.get(b8, 4)
+        out = []
+        for alt in ([rb] if kind == 1 else [a for a in range(5) if a != rb]):
+            c = int(v[1 + 2 * alt]) + int(v[2 + 2 * alt])
+            if kind == 2 and c == 0:
+                continue
+            f = [head] + (["ACGTN"[alt]] if kind == 2 else [])
+            if cols & (1 if kind == 1 else 2):
+                f.append(str(int(v[0])))
+            if cols & 64:
+                f.append(str(c))
+            if cols & 128:
+                f.append("0")
+            out.append("\t".join(f) + "\n")
+        return out
+
     with snp.PileupJob(opts, ref_lens, names) as job:
         job.set_bed(bed)
         job.submit(batch)
@@ -504,17 +526,17 @@ def test_rows_to_text_on_device():
             seq = np.array([rng.choice([1, 2, 4, 8, 15, 5, 0]) for _ in range(ref_lens[r])], np.uint8)
             start = int(pos[lo])
             job.set_ref_seq8(r, start, seq[start:int(pos[hi - 1]) + 1])
-            want = b"".join(
-                ("%s\t%d\t%s\t%s\n" % (names[r], pos[i] + 1, ascii_of[seq[pos[i]] & 15],
-                                       "\t".join(str(int(c)) for c in vals[i, 1:9]))).encode()
-                for i in range(lo, hi))
-            assert job.render_text(lo, hi - lo) == want
-            # a sub-range that starts and ends inside tiles of the scan
-            a, b = lo + 700, min(hi, lo + 2900)
-            got = job.render_text(a, b - a)
-            assert got == b"".join(want.splitlines(keepends=True)[a - lo:b - lo])
+            for kind, cols in [(0, 0), (1, 1 | 64 | 128), (2, 2 | 64 | 128), (1, 0), (2, 0), (1, 64), (2, 2), (2, 1 | 128)]:
+                per_row = [lines(kind, cols, names[r], int(pos[i]), int(seq[pos[i]]), vals[i]) for i in range(lo, hi)]
+                want = "".join("".join(x) for x in per_row).encode()
+                assert job.render_text(lo, hi - lo, kind, cols) == want, (r, kind, cols)
+                # a sub-range that starts and ends inside tiles of the scan
+                a, b = lo + 700, min(hi, lo + 2900)
+                assert job.render_text(a, b - a, kind, cols) == "".join("".join(x) for x in per_row[a - lo:b - lo]).encode()
             assert job.render_text(lo, 0) == b""
             # rows of the other reference have no base to show
             other = (n0, 5) if r == 0 else (0, 5)
             with pytest.raises(snp.PileupError, match="no reference base"):
                 job.render_text(*other)
+        with pytest.raises(snp.PileupError, match="per-read columns"):
+            job.render_text(n0, 5, 1, 8)

@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <future>
 #include <thread>
@@ -59,6 +60,7 @@ struct BamReader::Impl {
   std::vector<uint8_t> buf;  // inflated bytes not yet consumed: [rd, buf.size())
   size_t rd = 0;
   uint64_t file_pos = 0;  // file offset of the next byte fread returns
+  double wait_s = 0;      // time the consumer waited for inflated batches
   // (offset in buf, file offset) of the blocks buf holds bytes of, ascending
   std::vector<std::pair<size_t, uint64_t>> marks;
 
@@ -159,7 +161,9 @@ struct BamReader::Impl {
   // Appends the next batch behind the unconsumed tail and starts reading the one after it.
   std::string Refill() {
     if (!file_eof && buf.size() - rd <= kHead) {
+      const auto w0 = std::chrono::steady_clock::now();
       std::unique_ptr<Batch> b = next.valid() ? next.get() : ReadBatch(file_pos);
+      wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       if (!b->err.empty()) return b->err;
       const size_t tail = buf.size() - rd, at = kHead - tail;
       if (tail) memcpy(b->data.data() + at, buf.data() + rd, tail);
@@ -271,6 +275,15 @@ uint64_t BamReader::BlockOffset() const {
     at = mk.second;
   }
   return at;
+}
+
+double BamReader::WaitSeconds() const { return impl_->wait_s; }
+
+bool BamReader::NextRefills() const {
+  const Impl& m = *impl_;
+  const size_t have = m.buf.size() - m.rd;
+  if (have < 4) return true;
+  return have < 4 + (size_t)U32(m.buf.data() + m.rd);
 }
 
 int BamReader::Next(Raw* r) {

@@ -54,14 +54,26 @@ struct BamHeader {
 };
 
 // Growable structure-of-arrays record batch; view() exposes it as a bp_record_batch.
+// std::allocator that leaves trivially constructible elements uninitialised on resize(): the
+// payload vectors below are sized first and filled by several threads afterwards, and zeroing
+// 13 GB (a chr1-size BAM) first was a second of a single core.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+
 struct RecordBatchBuilder {
   std::vector<int32_t> ref_id, pos, mate_ref_id, mate_pos;
   std::vector<uint16_t> flags;
   std::vector<uint8_t> mapq;
   std::vector<uint32_t> n_cigar, l_seq;
   std::vector<uint64_t> cigar_off, seq_off, qual_off, name_off;
-  std::vector<uint32_t> cigar;
-  std::vector<uint8_t> seq, qual, name;
+  std::vector<uint32_t, NoInitAlloc<uint32_t>> cigar;
+  std::vector<uint8_t, NoInitAlloc<uint8_t>> seq, qual, name;
   bool keep_names = true;
   int64_t size() const { return (int64_t)pos.size(); }
   void clear();
@@ -89,6 +101,11 @@ class BamReader {
     const uint8_t* aux; uint32_t l_aux;
   };
   int Next(Raw* r);
+  // True when the next Next() has to bring in more of the file first: the buffers move then,
+  // and the pointers of Raw records handed out so far stop being valid.
+  bool NextRefills() const;
+  // Seconds Next() spent waiting for the inflater (BIO_PILEUP_STATS).
+  double WaitSeconds() const;
   const std::string& err() const { return err_; }
   // Continues reading at a BGZF virtual offset (compressed block offset << 16 | offset inside
   // the inflated block), e.g. one taken from an index.

@@ -128,6 +128,79 @@ void AppendRecord(RecordBatchBuilder* b, const BamReader::Raw& r) {
   }
 }
 
+// The same for a run of records whose bytes still sit in the reader's buffer: offsets by one
+// serial pass, the copies on HostThreads() threads.
+void AppendRecords(RecordBatchBuilder* b, const std::vector<BamReader::Raw>& raws) {
+  const size_t m = raws.size();
+  if (m < 4096) {
+    for (const BamReader::Raw& r : raws) AppendRecord(b, r);
+    return;
+  }
+  const size_t n0 = (size_t)b->size();
+  size_t co = b->cigar.size(), so = b->seq.size(), qo = b->qual.size(), no = b->name.size();
+  b->cigar_off.resize(n0 + m);
+  b->seq_off.resize(n0 + m);
+  b->qual_off.resize(n0 + m);
+  if (b->keep_names) b->name_off.resize(n0 + m);
+  for (size_t i = 0; i < m; i++) {
+    const BamReader::Raw& r = raws[i];
+    b->cigar_off[n0 + i] = co;
+    b->seq_off[n0 + i] = so;
+    b->qual_off[n0 + i] = qo;
+    co += r.n_cigar;
+    so += ((size_t)r.l_seq + 1) / 2;
+    qo += r.l_seq;
+    if (b->keep_names) {
+      b->name_off[n0 + i] = no;
+      no += r.l_name;
+    }
+  }
+  b->ref_id.resize(n0 + m);
+  b->pos.resize(n0 + m);
+  b->mate_ref_id.resize(n0 + m);
+  b->mate_pos.resize(n0 + m);
+  b->flags.resize(n0 + m);
+  b->mapq.resize(n0 + m);
+  b->n_cigar.resize(n0 + m);
+  b->l_seq.resize(n0 + m);
+  b->cigar.resize(co);
+  b->seq.resize(so);
+  b->qual.resize(qo);
+  if (b->keep_names) b->name.resize(no);
+  constexpr size_t kChunk = 2048;
+  const size_t n_chunks = (m + kChunk - 1) / kChunk;
+  const size_t nt = std::min<size_t>((size_t)std::max(1, HostThreads()), n_chunks);
+  auto work = [&](size_t t) {
+    for (size_t c = t; c < n_chunks; c += nt) {
+      for (size_t i = c * kChunk; i < std::min(m, (c + 1) * kChunk); i++) {
+        const BamReader::Raw& r = raws[i];
+        const size_t k = n0 + i;
+        b->ref_id[k] = r.ref_id;
+        b->pos[k] = r.pos;
+        b->mate_ref_id[k] = r.mate_ref_id;
+        b->mate_pos[k] = r.mate_pos;
+        b->flags[k] = r.flags;
+        b->mapq[k] = r.mapq;
+        b->n_cigar[k] = r.n_cigar;
+        b->l_seq[k] = r.l_seq;
+        if (r.n_cigar) memcpy(b->cigar.data() + b->cigar_off[k], r.cigar, 4 * (size_t)r.n_cigar);
+        if (r.l_seq) {
+          memcpy(b->seq.data() + b->seq_off[k], r.seq, ((size_t)r.l_seq + 1) / 2);
+          memcpy(b->qual.data() + b->qual_off[k], r.qual, r.l_seq);
+        }
+        if (b->keep_names && r.l_name) memcpy(b->name.data() + b->name_off[k], r.name, r.l_name);
+      }
+    }
+  };
+  if (nt <= 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+}
+
 class Driver {
  public:
   Driver(const Opts& o, const BamHeader& hd, const BEDUnion& bed, int fmt_ignore_strand)
@@ -540,6 +613,23 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   const double t_start = Now();
   std::deque<RecordBatchBuilder> pend(1);
   pend[0].keep_names = true;  // stitching keys on names; error messages quote them
+  // Records are first only noted (pointers into the reader's buffer), then copied into the
+  // builders many at a time and on several threads, before the reader's buffer moves.
+  std::deque<std::vector<BamReader::Raw>> raw(1);
+  double copy_s = 0;
+  auto flush_raw = [&]() {
+    const double f0 = Now();
+    struct Acc { double* s; double t0; ~Acc() { *s += Now() - t0; } } acc{&copy_s, f0};
+    for (size_t k = 0; k < raw.size(); k++) {
+      if (raw[k].empty()) continue;
+      while (pend.size() <= k) {
+        pend.emplace_back();
+        pend.back().keep_names = true;  // stitching keys on names; error messages quote them
+      }
+      AppendRecords(&pend[k], raw[k]);
+      raw[k].clear();
+    }
+  };
   size_t ji = 0;
   bool open = false;
   std::string err;
@@ -550,6 +640,9 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   };
   Closer closer(&drv);
   auto close_job = [&]() -> std::string {
+    flush_raw();
+    if (!raw.empty()) raw.pop_front();
+    if (raw.empty()) raw.emplace_back();
     double t0 = Now();
     std::string e = drv.Submit(&pend[0]);
     st.submit_s += Now() - t0;
@@ -583,6 +676,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     }
   }
   while (err.empty() && !no_records && ji < jobs.size()) {
+    if (bam.NextRefills()) flush_raw();
     int rc = bam.Next(&r);
     if (rc < 0) { err = bam.err(); break; }
     if (rc == 0) break;
@@ -608,6 +702,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
         skip_ref = nref;
         skip_pos = nstart;
         if ((voff >> 16) > bam.BlockOffset()) {
+          flush_raw();
           if (!(err = bam.Seek(voff)).empty()) break;
           st.seeks++;
         }
@@ -640,16 +735,14 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     // they go through the library's read checks as they do in whichever reference job
     // scans them.
     if (!open && !(err = open_job()).empty()) break;
-    AppendRecord(&pend[0], r);
+    raw[0].push_back(r);
     st.records_kept++;
     for (size_t k = ji + 1; k < jobs.size() && jobs[k].ref == r.ref_id && (int64_t)jobs[k].start - pad <= r.pos; k++) {
-      if (pend.size() <= k - ji) {
-        pend.emplace_back();
-        pend.back().keep_names = true;  // stitching keys on names; error messages quote them
-      }
-      AppendRecord(&pend[k - ji], r);
+      if (raw.size() <= k - ji) raw.emplace_back();
+      raw[k - ji].push_back(r);
     }
-    if (pend[0].size() >= kSubmitRecords) {
+    if (pend[0].size() + (int64_t)raw[0].size() >= kSubmitRecords) {
+      flush_raw();
       const double t0 = Now();
       err = drv.Submit(&pend[0]);
       st.submit_s += Now() - t0;
@@ -681,10 +774,11 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
-            "submit_s=%.3f close_s=%.3f (on its own thread; the reader waited %.3f s for it) read_s=%.3f total_s=%.3f\n",
+            "submit_s=%.3f close_s=%.3f (on its own thread; the reader waited %.3f s for it) read_s=%.3f "
+            "(of which waiting for inflated blocks %.3f, copying records %.3f) total_s=%.3f\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
             index.loaded() ? 1 : 0, st.submit_s, st.close_s, st.close_wait_s,
-            st.total_s - st.submit_s - st.close_wait_s, st.total_s);
+            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), copy_s, st.total_s);
   return "";
 }
 

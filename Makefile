@@ -20,7 +20,7 @@ oracle:
 	$(MAKE) -s -C oracle
 
 bio_amd/libbiopileup.so: $(LIB_SRCS) $(LIB_HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRCS) -lz -lpthread
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRCS) -lz -lpthread -ldl
 
 bio_amd/bio-pileup: $(CSRC)/cmd/bio_pileup_main.cpp bio_amd/libbiopileup.so
 	$(CXX) -O2 -std=c++17 -o $@ $(CSRC)/cmd/bio_pileup_main.cpp -Lbio_amd -lbiopileup -Wl,-rpath,'$$ORIGIN'
@@ -36,4 +36,4 @@ clean:
 # diagnostic build with in-kernel phase stamps (never shipped; see tools/phase_stamps.py)
 stamps: bio_amd/libbiopileup_stamps.so
 bio_amd/libbiopileup_stamps.so: $(LIB_SRCS) $(LIB_HDRS)
-	$(HIPCC) $(HIPFLAGS) -DBP_STAMPS $(STAMPFLAGS) -shared -o $@ $(LIB_SRCS) -lz -lpthread
+	$(HIPCC) $(HIPFLAGS) -DBP_STAMPS $(STAMPFLAGS) -shared -o $@ $(LIB_SRCS) -lz -lpthread -ldl

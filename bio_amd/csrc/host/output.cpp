@@ -4,6 +4,8 @@
 // tsv.Writer (grailbio/base, not in the reference tree) is restated from its observable
 // behaviour in cmd/bio-pileup/testdata/*.expected: every Write* appends the field and a tab,
 // EndLine turns the trailing tab into a newline.
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -23,6 +25,30 @@ const uint8_t kSeq8ToEnum[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4}
 const char kEnumToASCII[5] = {'A', 'C', 'G', 'T', 'N'};                                                           // common.go:69
 const char kStrandToASCII[3] = {'.', '+', '-'};                                                                   // common.go:91
 constexpr int kPerReadMask = kColEndDists | kColQuals | kColFraglens | kColStrands;                               // pileup.go:146
+
+// libdeflate for the BGZF members when the system has its runtime library (see bam.cpp: looked
+// up with dlopen, zlib otherwise, BIO_PILEUP_ZLIB=1 forces zlib).
+struct DeflateOut {
+  void* (*alloc)(int) = nullptr;
+  size_t (*compress)(void*, const void*, size_t, void*, size_t) = nullptr;
+  void (*free_)(void*) = nullptr;
+  uint32_t (*crc32_)(uint32_t, const void*, size_t) = nullptr;
+  bool ok = false;
+  DeflateOut() {
+    if (const char* e = getenv("BIO_PILEUP_ZLIB"); e && *e && *e != '0') return;
+    void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    alloc = (void* (*)(int))dlsym(h, "libdeflate_alloc_compressor");
+    compress = (size_t (*)(void*, const void*, size_t, void*, size_t))dlsym(h, "libdeflate_deflate_compress");
+    free_ = (void (*)(void*))dlsym(h, "libdeflate_free_compressor");
+    crc32_ = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+    ok = alloc && compress && free_ && crc32_;
+  }
+};
+const DeflateOut& GetDeflateOut() {
+  static const DeflateOut d;
+  return d;
+}
 
 // Byte sink: plain file, or BGZF (public SAM-spec container: <=64 KiB gzip members with a
 // BC extra subfield and an empty EOF member), compressed a batch of blocks at a time.
@@ -134,29 +160,40 @@ class Sink {
     if (nblk == 0) return "";
     std::vector<std::string> out(nblk);
     std::vector<int> bad(nblk, 0);
+    const DeflateOut& ld = GetDeflateOut();
     auto work = [&](size_t t, size_t nt) {
+      void* comp = ld.ok ? ld.alloc(level_ == Z_DEFAULT_COMPRESSION ? 6 : level_) : nullptr;
+      struct FreeComp { const DeflateOut& d; void* p; ~FreeComp() { if (p) d.free_(p); } } free_comp{ld, comp};
       for (size_t b = t; b < nblk; b += nt) {
         const size_t off = b * kBlock, len = std::min(kBlock, pend_.size() - off);
         std::string& o = out[b];
         o.resize(18 + compressBound((uLong)len) + 8);
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[b] = 1; continue; }
-        zs.next_in = (Bytef*)pend_.data() + off;
-        zs.avail_in = (uInt)len;
-        zs.next_out = (Bytef*)o.data() + 18;
-        zs.avail_out = (uInt)(o.size() - 18);
-        int rc = deflate(&zs, Z_FINISH);
-        size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) { bad[b] = 1; continue; }
+        size_t clen = 0;
+        if (comp) {
+          clen = ld.compress(comp, pend_.data() + off, len, &o[18], o.size() - 18 - 8);
+          if (clen == 0) { bad[b] = 1; continue; }
+        } else {
+          z_stream zs;
+          memset(&zs, 0, sizeof(zs));
+          if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[b] = 1; continue; }
+          zs.next_in = (Bytef*)pend_.data() + off;
+          zs.avail_in = (uInt)len;
+          zs.next_out = (Bytef*)o.data() + 18;
+          zs.avail_out = (uInt)(o.size() - 18);
+          int rc = deflate(&zs, Z_FINISH);
+          clen = zs.total_out;
+          deflateEnd(&zs);
+          if (rc != Z_STREAM_END) { bad[b] = 1; continue; }
+        }
+        if (18 + clen + 8 > 65536) { bad[b] = 1; continue; }
         uint8_t* h = (uint8_t*)o.data();
         const uint8_t hd[12] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0};
         memcpy(h, hd, 12);
         h[12] = 'B'; h[13] = 'C'; h[14] = 2; h[15] = 0;
         const size_t bsize = 18 + clen + 8 - 1;
         h[16] = (uint8_t)(bsize & 0xff); h[17] = (uint8_t)(bsize >> 8);
-        uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef*)pend_.data() + off, (uInt)len);
+        uint32_t crc = comp ? ld.crc32_(0, pend_.data() + off, len)
+                            : (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef*)pend_.data() + off, (uInt)len);
         uint8_t* tl = h + 18 + clen;
         for (int i = 0; i < 4; i++) tl[i] = (uint8_t)(crc >> (8 * i));
         for (int i = 0; i < 4; i++) tl[4 + i] = (uint8_t)((uint32_t)len >> (8 * i));

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <future>
 #include <mutex>
 #include <thread>
 #include <chrono>
@@ -29,7 +30,15 @@ namespace bio {
 
 namespace {
 
-constexpr int64_t kSubmitRecords = 1 << 20;  // records per bp_submit
+constexpr int64_t kSubmitRecordsDefault = 1 << 20;  // records per bp_submit
+int64_t SubmitRecords() {  // BIO_PILEUP_SUBMIT_RECORDS exists for tests of the batch hand-over
+  const char* e = getenv("BIO_PILEUP_SUBMIT_RECORDS");
+  if (e && *e) {
+    long long v = atoll(e);
+    if (v > 0) return v;
+  }
+  return kSubmitRecordsDefault;
+}
 constexpr int64_t kRowChunk = 1 << 20;       // rows per bp_rows copy
 // With an index, stretches of the BAM that start more than this many positions before the
 // next padded BED interval are skipped (the reference's position shards are this long, and
@@ -638,13 +647,27 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     open = e.empty();
     return e;
   };
+  const int64_t submit_records = SubmitRecords();
   Closer closer(&drv);
+  // A full batch is packed and copied to the device (bp_submit) on a thread of its own while
+  // the main thread goes on reading into the other builder; one batch in flight at most.
+  RecordBatchBuilder inflight;
+  inflight.keep_names = true;
+  std::future<std::string> submitting;
+  auto wait_submit = [&]() -> std::string {
+    if (!submitting.valid()) return "";
+    const double t0 = Now();
+    std::string e = submitting.get();
+    st.submit_s += Now() - t0;
+    return e;
+  };
   auto close_job = [&]() -> std::string {
     flush_raw();
     if (!raw.empty()) raw.pop_front();
     if (raw.empty()) raw.emplace_back();
+    std::string e = wait_submit();
     double t0 = Now();
-    std::string e = drv.Submit(&pend[0]);
+    if (e.empty()) e = drv.Submit(&pend[0]);
     st.submit_s += Now() - t0;
     t0 = Now();
     if (e.empty()) e = closer.Push(jobs[ji], drv.TakeHandles(), drv.open_rows);
@@ -741,14 +764,15 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
       if (raw.size() <= k - ji) raw.emplace_back();
       raw[k - ji].push_back(r);
     }
-    if (pend[0].size() + (int64_t)raw[0].size() >= kSubmitRecords) {
+    if (pend[0].size() + (int64_t)raw[0].size() >= submit_records) {
       flush_raw();
-      const double t0 = Now();
-      err = drv.Submit(&pend[0]);
-      st.submit_s += Now() - t0;
-      if (!err.empty()) break;
+      if (!(err = wait_submit()).empty()) break;
+      std::swap(inflight, pend[0]);  // (Submit left the other one empty)
+      submitting = std::async(std::launch::async, [&drv, &inflight] { return drv.Submit(&inflight); });
     }
   }
+  if (err.empty()) err = wait_submit();
+  else (void)wait_submit();
   // jobs after the last record still emit their (zero) rows (flushEmptyContigs,
   // pileup_support.go:112-123)
   while (err.empty() && ji < jobs.size()) {

@@ -276,6 +276,12 @@ def test_job_cuts_with_halo_change_nothing(tmp_path, stitch, monkeypatch):
         monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(span))
         host.pileup(c.bam, c.fa, "basestrand-tsv", str(tmp_path / "cut"), o)
         assert c.read("cut.basestrand.tsv") == want, span
+    # and many small submits (each handed to the submitting thread while reading goes on)
+    monkeypatch.setenv("BIO_PILEUP_SUBMIT_RECORDS", "97")
+    for span in (700, 1 << 26):
+        monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(span))
+        host.pileup(c.bam, c.fa, "basestrand-tsv", str(tmp_path / "sub"), o)
+        assert c.read("sub.basestrand.tsv") == want, span
 
 
 def test_per_strand(tmp_path):

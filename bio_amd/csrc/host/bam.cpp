@@ -76,7 +76,7 @@ const Deflate& GetDeflate() {
   return d;
 }
 
-constexpr int kBatchBlocks = 256;  // up to 16 MiB inflated per refill
+constexpr int kBatchBlocks = 256;  // up to 16 MiB inflated per refill (8 and 64 MiB are slower)
 // A batch's inflated bytes start kHead bytes into its buffer: the unconsumed tail of the previous
 // batch (normally part of one record) is copied in front of them and the buffers are swapped,
 // instead of appending 16 MiB to the old one.
@@ -86,7 +86,7 @@ constexpr size_t kHead = 1 << 20;
 struct BamReader::Impl {
   FILE* f = nullptr;
   bool file_eof = false;     // the batch reader met the end of the file
-  std::vector<uint8_t> buf;  // inflated bytes not yet consumed: [rd, buf.size())
+  std::vector<uint8_t, NoInitAlloc<uint8_t>> buf;  // inflated bytes not yet consumed: [rd, buf.size())
   size_t rd = 0;
   uint64_t file_pos = 0;  // file offset of the next byte fread returns
   double wait_s = 0;      // time the consumer waited for inflated batches
@@ -96,7 +96,7 @@ struct BamReader::Impl {
   // One batch of BGZF blocks, read and inflated off the main thread while the records of the
   // previous batch are decoded.
   struct Batch {
-    std::vector<uint8_t> data;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> data;  // (sized, then filled by the inflaters: not zeroed first)
     std::vector<std::pair<size_t, uint64_t>> marks;  // (offset in data, file offset)
     bool eof = false;
     uint64_t end_pos = 0;  // file offset behind the batch
@@ -114,7 +114,7 @@ struct BamReader::Impl {
     Batch& B = *out;
     struct Blk { size_t off, clen, isize, out; };
     std::vector<Blk> blks;
-    std::vector<uint8_t> raw;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> raw;
     size_t out_total = 0;
     uint64_t pos = at;
     while ((int)blks.size() < kBatchBlocks) {

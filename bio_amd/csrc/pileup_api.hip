@@ -32,7 +32,8 @@ void launch_pileup(const KernelParams& P, hipStream_t s);
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s);
 void launch_rows_add(uint32_t* rows, const uint32_t* src, int64_t n_u32, hipStream_t s);
 int window_size();
-void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned long long* tile_sum, hipStream_t s);
+void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned long long* tile_sum,
+                      int32_t* overflow, hipStream_t s);
 void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s);
 void launch_text(const TextParams& T, hipStream_t s);
 void launch_text_write(const TextParams& T, hipStream_t s);
@@ -892,26 +893,24 @@ int bp_per_read_build(bp_handle* h) {
   const int64_t n = 4 * h->n_rows;
   const int64_t n_tiles = (n + 1023) / 1024;
   if (int rc = ensure(h, h->d_pr_off, (size_t)n * 4 + 256, 0)) return rc;
-  if (int rc = ensure(h, h->d_pr_tiles, (size_t)n_tiles * 8 + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_pr_tiles, (size_t)(n_tiles + 1) * 8 + 256, 0)) return rc;
+  if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
   uint32_t* off32 = (uint32_t*)h->d_pr_off.p;
   HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
-  launch_tile_scan((const uint32_t*)h->d_rows.p, off32, n, (unsigned long long*)h->d_pr_tiles.p, h->stream);
+  HIP_TRY(h, hipMemsetAsync(h->d_err.p, 0, 4, h->stream));
+  // lengths -> in-tile offsets and tile totals -> tile bases, all on the device; only the total
+  // (it sizes the lists) and the overflow flag come back
+  launch_tile_scan((const uint32_t*)h->d_rows.p, off32, n, (unsigned long long*)h->d_pr_tiles.p, (int32_t*)h->d_err.p,
+                   h->stream);
   HIP_TRY(h, hipGetLastError());
-  std::vector<unsigned long long>& tiles = h->pr_tile_base;  // kept: bp_per_read_offsets adds them on the host
-  tiles.assign((size_t)n_tiles, 0);
-  if (n_tiles)
-    HIP_TRY(h, hipMemcpyAsync(tiles.data(), h->d_pr_tiles.p, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
   unsigned long long run = 0;
-  for (auto& t : tiles) {
-    const unsigned long long v = t;
-    if (v > 0xffffffffull) return fail(h, BP_EINVAL, "bp_per_read_build: more than 2^32 list entries on 256 positions");
-    t = run;
-    run += v;
-  }
+  int32_t overflow = 0;
+  HIP_TRY(h, hipMemcpyAsync(&run, (const unsigned long long*)h->d_pr_tiles.p + n_tiles, 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&overflow, h->d_err.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (overflow) return fail(h, BP_EINVAL, "bp_per_read_build: more than 2^32 list entries on 256 positions");
   h->n_feat = run;
-  if (n_tiles)
-    HIP_TRY(h, hipMemcpyAsync(h->d_pr_tiles.p, tiles.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, h->stream));
+  h->pr_tile_base.clear();  // fetched when bp_per_read_offsets first needs them
   // + 128 entries of slack behind the last list (see the cursor check in per_read_kernel)
   if (int rc = ensure(h, h->d_pr_feat, ((size_t)run + 128) * sizeof(PerRead) + 256, 0)) return rc;
   const size_t n_iv = h->iv_ref.size();
@@ -967,6 +966,11 @@ int bp_per_read_offsets(bp_handle* h, int64_t first_row, int64_t n_rows, uint64_
                 (long long)(first_row + n_rows), (long long)h->n_rows);
   HIP_TRY(h, hipSetDevice(h->device));
   const int64_t i0 = 4 * first_row, m = 4 * n_rows;
+  if (h->pr_tile_base.empty()) {
+    const size_t n_tiles = (size_t)((4 * h->n_rows + 1023) / 1024);
+    h->pr_tile_base.assign(n_tiles + 1, 0);
+    HIP_TRY(h, hipMemcpy(h->pr_tile_base.data(), h->d_pr_tiles.p, (n_tiles + 1) * 8, hipMemcpyDeviceToHost));
+  }
   std::vector<uint32_t> rel((size_t)m);
   if (m) HIP_TRY(h, hipMemcpy(rel.data(), (const uint32_t*)h->d_pr_off.p + i0, (size_t)m * 4, hipMemcpyDeviceToHost));
   for (int64_t k = 0; k < m; k++) off[k] = h->pr_tile_base[(size_t)((i0 + k) >> 10)] + rel[(size_t)k];

@@ -1190,12 +1190,14 @@ __global__ void column_sums_kernel(const uint32_t* rows, int64_t n_rows, unsigne
 //            take a second, per-base ballot.  The lanes of one ballot are consecutive entries
 //            of one list, so every store instruction writes one contiguous run of the output.
 
+__global__ void text_tile_scan_kernel(unsigned long long* tile, int64_t n_tiles);  // exclusive scan by one workgroup (below)
+
 // List lengths (lens[4r + b] = Counts[b][0] + Counts[b][1] of row r, read straight from the
 // rows) scanned in tiles of 1024 lists: off32 gets the exclusive sum inside the tile, tile_sum
 // the tile's total.  The host scans the totals; a list's offset is tile_base[i >> 10] + off32[i]
 // (pr_off), so there is no second pass over the offsets.
 __global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* rows, uint32_t* off32, int64_t n,
-                                                        unsigned long long* tile_sum) {
+                                                        unsigned long long* tile_sum, int32_t* overflow) {
   __shared__ unsigned long long sh[256];
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 4 lists per row
   const int64_t base = row * 4;
@@ -1222,7 +1224,10 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const uint32_t* rows, ui
     o.w = (uint32_t)run;
     *(uint4*)(off32 + base) = o;
   }
-  if (threadIdx.x == 255) tile_sum[blockIdx.x] = sh[255];
+  if (threadIdx.x == 255) {
+    tile_sum[blockIdx.x] = sh[255];
+    if (sh[255] > 0xffffffffull) *overflow = 1;  // the in-tile offsets are 32 bits
+  }
 }
 
 // offset of list i (i = 4 x row + base; i = n_lists gives the total)
@@ -1601,9 +1606,13 @@ __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerR
   }
 }
 
-void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned long long* tile_sum, hipStream_t s) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, rows, off32, n, tile_sum);
+// tile_sum: [n_tiles + 1]; on return (stream order) tile_sum[t] = entries before tile t and
+// tile_sum[n_tiles] = entries in all lists.  *overflow is set when a tile holds 2^32 or more.
+void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned long long* tile_sum,
+                      int32_t* overflow, hipStream_t s) {
+  const int64_t n_tiles = (n + 1023) / 1024;
+  if (n) hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, rows, off32, n, tile_sum, overflow);
+  hipLaunchKernelGGL(text_tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_sum, n_tiles);
 }
 int per_read_tile_positions() { return kPrT; }
 void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s) {
@@ -1753,16 +1762,22 @@ __global__ __launch_bounds__(256) void text_len_kernel(TextParams T) {
   if (threadIdx.x == 255) T.tile[blockIdx.x] = sh[255];
 }
 
-// exclusive scan of the tile totals by one workgroup; tile[n_tiles] = length of the whole text
+// exclusive scan of the tile totals by one workgroup (8 per thread and step); tile[n_tiles] =
+// the grand total
 __global__ __launch_bounds__(1024) void text_tile_scan_kernel(unsigned long long* tile, int64_t n_tiles) {
   __shared__ unsigned long long sh[1024];
   __shared__ unsigned long long carry;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (int64_t b = 0; b < n_tiles; b += 1024) {
-    const int64_t i = b + threadIdx.x;
-    const unsigned long long v = i < n_tiles ? tile[i] : 0;
-    sh[threadIdx.x] = v;
+  for (int64_t b = 0; b < n_tiles; b += 8192) {
+    const int64_t i0 = b + (int64_t)threadIdx.x * 8;
+    unsigned long long v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      v[k] = i0 + k < n_tiles ? tile[i0 + k] : 0;
+      s += v[k];
+    }
+    sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
       const unsigned long long t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
@@ -1770,7 +1785,12 @@ __global__ __launch_bounds__(1024) void text_tile_scan_kernel(unsigned long long
       sh[threadIdx.x] += t;
       __syncthreads();
     }
-    if (i < n_tiles) tile[i] = carry + sh[threadIdx.x] - v;
+    unsigned long long run = carry + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (i0 + k < n_tiles) tile[i0 + k] = run;
+      run += v[k];
+    }
     __syncthreads();
     if (threadIdx.x == 1023) carry += sh[1023];
     __syncthreads();

@@ -74,6 +74,9 @@ HOST_EXPORTS = [
     "bio_pileup_default_opts", "bio_pileup_run", "bio_pileup_main", "bio_parse_region",
     "bio_parse_cols", "bio_bed_load", "bio_bed_endpoints", "bio_bed_intersects", "bio_bed_free",
     "bio_fasta_seq8", "bio_bam_scan", "bio_bam_seek_scan", "bio_bam_write",
+    "bio_pileup_write_rows", "bio_pileup_row_fields", "bio_marshal_pileup_row", "bio_unmarshal_pileup_row",
+    "bio_marshal_basestrand", "bio_unmarshal_basestrand", "bio_basestrand_rio_trailer",
+    "bio_parse_basestrand_rio_trailer", "bio_basestrand_piles_to_tsv",
 ]
 
 
@@ -201,5 +204,29 @@ def load():
     lib.bio_bam_write.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
                                   C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
     lib.bio_bam_write.restype = C.c_int
+    u32p, i32p = C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+    lib.bio_pileup_write_rows.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_char_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int64, i32p, i32p, u32p,
+                                          C.POINTER(C.c_uint64), C.c_void_p] + E
+    lib.bio_pileup_write_rows.restype = C.c_int
+    lib.bio_pileup_row_fields.argtypes = [u32p, u32p, C.c_int32]
+    lib.bio_pileup_row_fields.restype = C.c_uint32
+    lib.bio_marshal_pileup_row.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, C.POINTER(C.c_void_p),
+                                           C.c_void_p, C.c_size_t]
+    lib.bio_marshal_pileup_row.restype = C.c_int64
+    lib.bio_unmarshal_pileup_row.argtypes = [C.c_void_p, C.c_size_t, u32p, u32p, u32p, u32p, u32p, C.c_void_p,
+                                             C.c_size_t]
+    lib.bio_unmarshal_pileup_row.restype = C.c_int64
+    lib.bio_marshal_basestrand.argtypes = [C.c_int64, i32p, i32p, u32p, C.c_void_p]
+    lib.bio_marshal_basestrand.restype = None
+    lib.bio_unmarshal_basestrand.argtypes = [C.c_int64, C.c_void_p, i32p, i32p, u32p]
+    lib.bio_unmarshal_basestrand.restype = None
+    lib.bio_basestrand_rio_trailer.argtypes = [C.c_int64, C.c_void_p]
+    lib.bio_basestrand_rio_trailer.restype = None
+    lib.bio_parse_basestrand_rio_trailer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)] + E
+    lib.bio_parse_basestrand_rio_trailer.restype = C.c_int
+    lib.bio_basestrand_piles_to_tsv.argtypes = [C.c_int64, i32p, i32p, u32p, C.c_int32, C.POINTER(C.c_char_p),
+                                                C.c_char_p, C.c_void_p, C.c_size_t]
+    lib.bio_basestrand_piles_to_tsv.restype = C.c_int64
     _lib = lib
     return lib

@@ -189,6 +189,44 @@ int bio_bam_seek_scan(const char* bam_path, const char* index_path, int32_t ref_
   return Ok(err, errlen);
 }
 
+int bio_pileup_write_rows(const char* format, const char* out_prefix, const char* cols, int32_t n_ref,
+                          const char* const* ref_names, const uint8_t* const* ref_seq8, const int64_t* ref_seq_len,
+                          int64_t n_rows, const int32_t* ref_id, const int32_t* pos, const uint32_t* vals,
+                          const uint64_t* off, const bp_per_read* feats, char* err, size_t errlen) {
+  if (!format || !out_prefix || n_ref < 0 || n_rows < 0 || (n_ref && (!ref_names || !ref_seq8 || !ref_seq_len)) ||
+      (n_rows && (!ref_id || !pos || !vals)))
+    return Fail("bio_pileup_write_rows: null argument", err, errlen);
+  const std::string fmt = format;
+  const bool tsv = fmt == "tsv" || fmt == "tsv-bgz", bs = fmt == "basestrand-tsv" || fmt == "basestrand-tsv-bgz";
+  if (!tsv && !bs) return Fail("Pileup: unrecognized format= argument", err, errlen);
+  const bool bgz = fmt == "tsv-bgz" || fmt == "basestrand-tsv-bgz";
+  const int cols_default = bio::kColDpRef | bio::kColHighQ | bio::kColLowQ;  // pileup.go:1015
+  int bits = cols_default;
+  if (cols && *cols) {
+    std::string m = bio::ParseCols(cols, cols_default, &bits);
+    if (!m.empty()) return Fail(m, err, errlen);
+  }
+  std::vector<std::string> names, seqs((size_t)n_ref);
+  std::vector<const std::string*> seq_ptrs((size_t)n_ref, nullptr);
+  for (int32_t i = 0; i < n_ref; i++) {
+    names.push_back(Str(ref_names[i]));
+    if (ref_seq8[i]) {
+      seqs[(size_t)i].assign((const char*)ref_seq8[i], (size_t)ref_seq_len[i]);
+      seq_ptrs[(size_t)i] = &seqs[(size_t)i];
+    }
+  }
+  for (int64_t i = 0; i < n_rows; i++)
+    if (ref_id[i] < 0 || ref_id[i] >= n_ref) return Fail("bio_pileup_write_rows: row with reference id out of range", err, errlen);
+  std::string m;
+  std::unique_ptr<bio::RowWriter> w = tsv ? bio::NewTsvWriter(out_prefix, bits, bgz, names, seq_ptrs, &m)
+                                          : bio::NewBasestrandTsvWriter(out_prefix, bits, bgz, names, seq_ptrs, &m);
+  if (!m.empty()) return Fail(m, err, errlen);
+  if (n_rows) m = w->Write(ref_id, pos, vals, n_rows, off, feats);
+  const std::string c = w->Close();
+  if (m.empty()) m = c;
+  return m.empty() ? Ok(err, errlen) : Fail(m, err, errlen);
+}
+
 int bio_bam_write(const char* path, int32_t n_ref, const char* const* ref_names, const int32_t* ref_lens,
                   const bp_record_batch* batch, int32_t level, int32_t threads, char* err, size_t errlen) {
   if (!path || !batch || n_ref < 0) return Fail("bio_bam_write: bad argument", err, errlen);

@@ -139,3 +139,132 @@ def bam_write(path, ref_names, ref_lens, batch, level=1, threads=8):
     e = _err()
     if lib.bio_bam_write(path.encode(), len(ref_names), names, lens, C.byref(cb), level, threads, e, len(e)):
         raise ValueError(e.value.decode())
+
+
+def write_rows(fmt, out_prefix, cols, ref_names, ref_seq8, ref_id, pos, vals, off=None, feats=None):
+    """ConvertPileupRowsToTSV / ConvertPileupRowsToBasestrandTSV (output.go:42-300, :376-575) over
+    rows in memory, with the product's writers.  ref_seq8: one uint8 array (or None) per reference."""
+    lib = _abi.load()
+    names = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+    seqs = [None if s is None else np.ascontiguousarray(s, np.uint8) for s in ref_seq8]
+    sp = (C.c_void_p * len(seqs))(*[None if s is None else s.ctypes.data for s in seqs])
+    sl = (C.c_int64 * len(seqs))(*[0 if s is None else len(s) for s in seqs])
+    ref_id = np.ascontiguousarray(ref_id, np.int32)
+    pos = np.ascontiguousarray(pos, np.int32)
+    vals = np.ascontiguousarray(vals, np.uint32)
+    i32p = C.POINTER(C.c_int32)
+    offp = featp = None
+    if off is not None:
+        off = np.ascontiguousarray(off, np.uint64)
+        feats = np.ascontiguousarray(feats)
+        offp, featp = off.ctypes.data_as(C.POINTER(C.c_uint64)), feats.ctypes.data
+    e = _err()
+    if lib.bio_pileup_write_rows(fmt.encode(), out_prefix.encode(), _b(cols), len(ref_names), names, sp, sl, len(pos),
+                                 ref_id.ctypes.data_as(i32p), pos.ctypes.data_as(i32p),
+                                 vals.ctypes.data_as(C.POINTER(C.c_uint32)), offp, featp, e, len(e)):
+        raise PileupError(-1, e.value.decode())
+
+
+def row_fields(vals, list_len, per_read_needed):
+    """PileupRow.FieldsPresent as flushToInternal sets it (pileup.go:518-570)."""
+    lib = _abi.load()
+    v = np.ascontiguousarray(vals, np.uint32)
+    ll = np.ascontiguousarray(list_len, np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    return int(lib.bio_pileup_row_fields(v.ctypes.data_as(u32p), ll.ctypes.data_as(u32p), int(per_read_needed)))
+
+
+def marshal_pileup_row(fields, ref_id, pos, vals, lists=None):
+    """MarshalPileupRow (row.go:113-175) -> bytes.  lists: four arrays of snp.PER_READ_DTYPE."""
+    from .snp import PER_READ_DTYPE
+    lib = _abi.load()
+    v = np.ascontiguousarray(vals, np.uint32)
+    ls = [np.ascontiguousarray(x if x is not None else [], PER_READ_DTYPE) for x in (lists or [None] * 4)]
+    ll = np.array([len(x) for x in ls], np.uint32)
+    lp = (C.c_void_p * 4)(*[x.ctypes.data if len(x) else None for x in ls])
+    u32p = C.POINTER(C.c_uint32)
+    n = lib.bio_marshal_pileup_row(fields, ref_id, pos, v.ctypes.data_as(u32p), ll.ctypes.data_as(u32p), lp, None, 0)
+    if n < 0:
+        raise ValueError("bio_marshal_pileup_row: bad argument")
+    out = C.create_string_buffer(int(n))
+    lib.bio_marshal_pileup_row(fields, ref_id, pos, v.ctypes.data_as(u32p), ll.ctypes.data_as(u32p), lp, out, n)
+    return out.raw
+
+
+def unmarshal_pileup_row(data):
+    """unmarshalPileupRow (row.go:179-227) -> (fields, ref_id, pos, vals[11], [4 lists])"""
+    from .snp import PER_READ_DTYPE
+    lib = _abi.load()
+    f, r, p = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    vals = np.zeros(_abi.BP_ROW_U32, np.uint32)
+    ll = np.zeros(4, np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    buf = C.create_string_buffer(bytes(data), len(data))
+    feats = np.zeros(max(len(data) // 6, 1), PER_READ_DTYPE)
+    n = lib.bio_unmarshal_pileup_row(buf, len(data), C.byref(f), C.byref(r), C.byref(p), vals.ctypes.data_as(u32p),
+                                     ll.ctypes.data_as(u32p), feats.ctypes.data, len(feats))
+    if n < 0:
+        raise ValueError("unmarshalPileupRow: truncated record")
+    lists, o = [], 0
+    for b in range(4):
+        lists.append(feats[o:o + int(ll[b])].copy())
+        o += int(ll[b])
+    return f.value, r.value, p.value, vals, lists
+
+
+def marshal_basestrand(ref_id, pos, vals):
+    """marshalBaseStrand (basestrand.go:103-135) over n rows -> bytes (40 per row)"""
+    lib = _abi.load()
+    ref_id = np.ascontiguousarray(ref_id, np.int32)
+    pos = np.ascontiguousarray(pos, np.int32)
+    vals = np.ascontiguousarray(vals, np.uint32)
+    out = C.create_string_buffer(40 * len(pos) + 1)
+    i32p = C.POINTER(C.c_int32)
+    lib.bio_marshal_basestrand(len(pos), ref_id.ctypes.data_as(i32p), pos.ctypes.data_as(i32p),
+                               vals.ctypes.data_as(C.POINTER(C.c_uint32)), out)
+    return out.raw[:40 * len(pos)]
+
+
+def unmarshal_basestrand(data):
+    lib = _abi.load()
+    n = len(data) // 40
+    ref_id, pos, c8 = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros((n, 8), np.uint32)
+    buf = C.create_string_buffer(bytes(data), len(data))
+    i32p = C.POINTER(C.c_int32)
+    lib.bio_unmarshal_basestrand(n, buf, ref_id.ctypes.data_as(i32p), pos.ctypes.data_as(i32p),
+                                 c8.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return ref_id, pos, c8
+
+
+def basestrand_rio_trailer(num_piles):
+    lib = _abi.load()
+    out = C.create_string_buffer(16)
+    lib.bio_basestrand_rio_trailer(num_piles, out)
+    return out.raw
+
+
+def parse_basestrand_rio_trailer(data):
+    lib = _abi.load()
+    n, e = C.c_int64(), _err()
+    buf = C.create_string_buffer(bytes(data), len(data))
+    if lib.bio_parse_basestrand_rio_trailer(buf, len(data), C.byref(n), e, len(e)):
+        raise ValueError(e.value.decode())
+    return n.value
+
+
+def basestrand_piles_to_tsv(ref_id, pos, counts8, ref_names, ref_bases=None):
+    """WriteBaseStrandToTSV (ref_bases None) / WriteBaseStrandTsv (basestrand.go:204-231, :282-290)"""
+    lib = _abi.load()
+    ref_id = np.ascontiguousarray(ref_id, np.int32)
+    pos = np.ascontiguousarray(pos, np.int32)
+    c8 = np.ascontiguousarray(counts8, np.uint32)
+    names = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+    i32p = C.POINTER(C.c_int32)
+    args = (len(pos), ref_id.ctypes.data_as(i32p), pos.ctypes.data_as(i32p), c8.ctypes.data_as(C.POINTER(C.c_uint32)),
+            len(ref_names), names, None if ref_bases is None else "".join(ref_bases).encode())
+    n = lib.bio_basestrand_piles_to_tsv(*args, None, 0)
+    if n < 0:
+        raise ValueError("bio_basestrand_piles_to_tsv: reference id out of range")
+    out = C.create_string_buffer(int(n) + 1)
+    lib.bio_basestrand_piles_to_tsv(*args, out, n)
+    return out.raw[:n]

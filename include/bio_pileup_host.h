@@ -95,6 +95,53 @@ int bio_bam_seek_scan(const char* bam_path, const char* index_path, int32_t ref_
 int bio_bam_write(const char* path, int32_t n_ref, const char* const* ref_names, const int32_t* ref_lens,
                   const bp_record_batch* batch, int32_t level, int32_t threads, char* err, size_t errlen);
 
+/* ConvertPileupRowsToTSV (pileup/snp/output.go:42-300) and ConvertPileupRowsToBasestrandTSV
+ * (output.go:376-575) with the rows handed over in memory instead of in the per-job recordio
+ * temp files: writes <out_prefix>.ref.tsv + .alt.tsv (format "tsv"/"tsv-bgz") or
+ * <out_prefix>.basestrand.tsv ("basestrand-tsv"/"-bgz"), header included, with the product's
+ * writers (the ones bio_pileup_run uses).  cols = the -cols string ("" = dpref,highq,lowq,
+ * pileup.go:1015).  ref_seq8[r] = Seq8 bases of reference r (ref_seq_len[r] of them; may be NULL
+ * for references no row lies on).  vals = n_rows x BP_ROW_U32; off/feats = per-read lists as
+ * bp_per_read_offsets / bp_per_read_features give them (off[4*n_rows+1] absolute entry indices,
+ * feats pointing at entry off[0]); both NULL without a per-read column. */
+int bio_pileup_write_rows(const char* format, const char* out_prefix, const char* cols, int32_t n_ref,
+                          const char* const* ref_names, const uint8_t* const* ref_seq8, const int64_t* ref_seq_len,
+                          int64_t n_rows, const int32_t* ref_id, const int32_t* pos, const uint32_t* vals,
+                          const uint64_t* off, const bp_per_read* feats, char* err, size_t errlen);
+
+/* ---- record-level wire formats (the recordio container around them is grailbio/base's and is
+ * not built) */
+
+/* PileupRow.FieldsPresent as flushToInternal sets it (pileup/snp/pileup.go:518-570, bits
+ * row.go:33-40): 0 for a zero-depth row, else FieldCounts | FieldPerRead{A,C,G,T} for the
+ * non-empty lists when per_read_needed. */
+uint32_t bio_pileup_row_fields(const uint32_t* vals, const uint32_t list_len[4], int32_t per_read_needed);
+/* MarshalPileupRow (pileup/snp/row.go:113-175).  vals = BP_ROW_U32 uint32 (Depth, Counts);
+ * lists[b] = list_len[b] entries of base b.  Returns the record's size; writes it when out has
+ * room (out NULL or cap too small: size query), -1 on a bad argument. */
+int64_t bio_marshal_pileup_row(uint32_t fields_present, uint32_t ref_id, uint32_t pos, const uint32_t* vals,
+                               const uint32_t list_len[4], const bp_per_read* const lists[4], uint8_t* out,
+                               size_t cap);
+/* unmarshalPileupRow (row.go:179-227).  Returns the number of list entries (feats receives the
+ * first feats_cap of them, lists A,C,G,T back to back), -1 on a truncated record. */
+int64_t bio_unmarshal_pileup_row(const uint8_t* in, size_t len, uint32_t* fields_present, uint32_t* ref_id,
+                                 uint32_t* pos, uint32_t* vals, uint32_t list_len[4], bp_per_read* feats,
+                                 size_t feats_cap);
+/* marshalBaseStrand (pileup/snp/basestrand.go:103-135) for n rows: 40 bytes each, refID, pos,
+ * A+ A- C+ C- G+ G- T+ T- (vals = n x BP_ROW_U32 as bp_rows returns them). */
+void bio_marshal_basestrand(int64_t n, const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, uint8_t* out);
+/* BaseStrandUnmarshaller.UnmarshalBaseStrand (basestrand.go:183-201); counts8 = n x 8. */
+void bio_unmarshal_basestrand(int64_t n, const uint8_t* in, int32_t* ref_id, int32_t* pos, uint32_t* counts8);
+/* baseStrandsRioTrailer / parseBaseStrandsTrailer (basestrand.go:77-101) */
+void bio_basestrand_rio_trailer(int64_t num_piles, uint8_t out[16]);
+int bio_parse_basestrand_rio_trailer(const uint8_t* trailer, size_t len, int64_t* num_piles, char* err, size_t errlen);
+/* WriteBaseStrandToTSV (basestrand.go:204-231; ref_bases NULL: no REF column, no '#', POS as
+ * stored) or WriteBaseStrandTsv (basestrand.go:282-290; ref_bases[i] = REF of row i).  Returns
+ * the text's length; writes it when out has room. */
+int64_t bio_basestrand_piles_to_tsv(int64_t n, const int32_t* ref_id, const int32_t* pos, const uint32_t* counts8,
+                                    int32_t n_ref, const char* const* ref_names, const char* ref_bases, char* out,
+                                    size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,7 +64,7 @@ class bp_timing(C.Structure):
 
 EXPORTS = [
     "bp_init", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute",
-    "bp_num_rows", "bp_rows", "bp_rows_device", "bp_rows_export", "bp_rows_accumulate", "bp_column_sums", "bp_get_timing",
+    "bp_num_rows", "bp_rows", "bp_rows_device", "bp_rows_export", "bp_rows_accumulate", "bp_rows_export_async", "bp_rows_accumulate_async", "bp_stream", "bp_column_sums", "bp_get_timing",
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
     "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch",
@@ -143,6 +143,12 @@ def load():
     lib.bp_rows_export.restype = C.c_int
     lib.bp_rows_accumulate.argtypes = [H, C.c_int64, C.c_int64, C.c_void_p]
     lib.bp_rows_accumulate.restype = C.c_int
+    lib.bp_rows_export_async.argtypes = [H, C.c_int64, C.c_int64, C.c_void_p]
+    lib.bp_rows_export_async.restype = C.c_int
+    lib.bp_rows_accumulate_async.argtypes = [H, C.c_int64, C.c_int64, C.c_void_p]
+    lib.bp_rows_accumulate_async.restype = C.c_int
+    lib.bp_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.bp_stream.restype = C.c_int
     lib.bp_column_sums.argtypes = [H, C.POINTER(C.c_uint64)]
     lib.bp_column_sums.restype = C.c_int
     lib.bp_get_timing.argtypes = [H, C.POINTER(bp_timing)]

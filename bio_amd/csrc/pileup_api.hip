@@ -82,6 +82,11 @@ struct bp_handle {
   bool frozen = false;                    // BED fixed, windows built
   bool finished = false;
   std::string err;
+  // A bp_submit that failed part-way has already moved the order key, the per-reference record
+  // ranges, the coarse index and the mate table past records that were never committed: the
+  // job cannot go on.  The error sticks: later submit / compute / finish calls return it again.
+  int poison_code = 0;
+  std::string poison_msg;
 
   // flattened intervals + windows
   std::vector<int32_t> iv_ref, iv_start, iv_end;
@@ -568,9 +573,20 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
   if (b->n < 0) return fail(h, BP_EINVAL, "bp_submit: negative record count");
   if (h->o.stitch && b->n > 0 && (!b->name || !b->name_off))
     return fail(h, BP_EINVAL, "bp_submit: stitch mode needs read names (firstread.go:135-152)");
+  if (h->poison_code) return fail(h, h->poison_code, "%s", h->poison_msg.c_str());
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = freeze_bed(h)) return rc;
   h->rows_valid = false;
+  struct Poison {  // any error return below leaves the handle's bookkeeping half advanced
+    bp_handle* h;
+    bool armed = true;
+    ~Poison() {
+      if (armed && !h->poison_code) {
+        h->poison_code = BP_EINVAL;
+        h->poison_msg = "bp_submit: an earlier bp_submit of this job failed (" + h->err + "); the job cannot continue";
+      }
+    }
+  } poison{h};
   const int nthreads = pack_threads();
   std::vector<int32_t> spans;
   std::vector<uint8_t> simple;
@@ -681,6 +697,7 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
     h->blob_used += bytes / 8;
     i0 = i1;
   }
+  poison.armed = false;
   return BP_OK;
 }
 
@@ -728,6 +745,7 @@ static void fill_params(bp_handle* h, KernelParams& P) {
 
 int bp_compute(bp_handle* h) {
   if (!h) return fail(h, BP_EINVAL, "bp_compute: null handle");
+  if (h->poison_code) return fail(h, h->poison_code, "%s", h->poison_msg.c_str());
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = freeze_bed(h)) return rc;
   if (h->o.stitch) {
@@ -841,7 +859,13 @@ int bp_rows_device(bp_handle* h, const uint32_t** dptr) {
   return BP_OK;
 }
 
-int bp_rows_export(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device) {
+int bp_stream(bp_handle* h, void** stream) {
+  if (!h || !stream) return fail(h, BP_EINVAL, "bp_stream: null argument");
+  *stream = (void*)h->stream;
+  return BP_OK;
+}
+
+int bp_rows_export_async(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device) {
   if (!h || (n > 0 && !dst_device)) return fail(h, BP_EINVAL, "bp_rows_export: null argument");
   if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_rows_export: no computed rows");
   if (first < 0 || n < 0 || first + n > h->n_rows)
@@ -851,11 +875,16 @@ int bp_rows_export(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device)
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipMemcpyAsync(dst_device, (const uint32_t*)h->d_rows.p + first * BP_ROW_U32,
                             (size_t)n * BP_ROW_U32 * 4, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return BP_OK;
 }
 
-int bp_rows_accumulate(bp_handle* h, int64_t first, int64_t n, const uint32_t* src_device) {
+int bp_rows_export(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device) {
+  if (int rc = bp_rows_export_async(h, first, n, dst_device)) return rc;
+  if (n > 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return BP_OK;
+}
+
+int bp_rows_accumulate_async(bp_handle* h, int64_t first, int64_t n, const uint32_t* src_device) {
   if (!h || (n > 0 && !src_device)) return fail(h, BP_EINVAL, "bp_rows_accumulate: null argument");
   if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_rows_accumulate: no computed rows");
   if (first < 0 || n < 0 || first + n > h->n_rows)
@@ -865,8 +894,13 @@ int bp_rows_accumulate(bp_handle* h, int64_t first, int64_t n, const uint32_t* s
   HIP_TRY(h, hipSetDevice(h->device));
   launch_rows_add((uint32_t*)h->d_rows.p + first * BP_ROW_U32, src_device, n * BP_ROW_U32, h->stream);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->per_read_valid = false;
+  return BP_OK;
+}
+
+int bp_rows_accumulate(bp_handle* h, int64_t first, int64_t n, const uint32_t* src_device) {
+  if (int rc = bp_rows_accumulate_async(h, first, n, src_device)) return rc;
+  if (n > 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
   return BP_OK;
 }
 

@@ -161,6 +161,21 @@ class PileupJob:
         """rows [first, first+n) += n*11 uint32 at a device address (boundary exchange)"""
         self._check(self.lib.bp_rows_accumulate(self.h, first, n, src_device_ptr))
 
+    def rows_export_async(self, first, n, dst_device_ptr):
+        """rows_export, only enqueued on the job's stream"""
+        self._check(self.lib.bp_rows_export_async(self.h, first, n, dst_device_ptr))
+
+    def rows_accumulate_async(self, first, n, src_device_ptr):
+        """rows_accumulate, only enqueued on the job's stream"""
+        self._check(self.lib.bp_rows_accumulate_async(self.h, first, n, src_device_ptr))
+
+    @property
+    def stream(self):
+        """the job's hipStream_t as an integer (torch.cuda.ExternalStream takes it)"""
+        p = C.c_void_p()
+        self._check(self.lib.bp_stream(self.h, C.byref(p)))
+        return p.value or 0
+
     def column_sums(self):
         s = (C.c_uint64 * _abi.BP_ROW_U32)()
         self._check(self.lib.bp_column_sums(self.h, s))

@@ -162,6 +162,13 @@ int bp_rows_device(bp_handle* h, const uint32_t** dptr);
  * jobs re-read a halo of records instead, pileup.go:896-909). */
 int bp_rows_export(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device);
 int bp_rows_accumulate(bp_handle* h, int64_t first, int64_t n, const uint32_t* src_device);
+/* The same two, only enqueued on the job's stream (no wait): for an exchange that is ordered
+ * against the collective with stream events instead of host synchronisations.  bp_stream
+ * hands out that stream (a hipStream_t; kernels, copies and these calls of one handle all run
+ * on it, in call order) so that the caller can make its own stream wait for it and back. */
+int bp_rows_export_async(bp_handle* h, int64_t first, int64_t n, uint32_t* dst_device);
+int bp_rows_accumulate_async(bp_handle* h, int64_t first, int64_t n, const uint32_t* src_device);
+int bp_stream(bp_handle* h, void** stream);
 
 /* Sum over all rows of each of the BP_ROW_U32 columns (uint64 each), reduced on device.
  * Size-independent parity check: sums[0] = total depth. */

@@ -207,6 +207,15 @@ def test_errors_match_reference_wording():
     a = dict(base, cigar=[("M", 5)], seq="AAAAA", qual=[30] * 5)
     with pytest.raises(snp.PileupError, match="out of coordinate order"):
         device_rows(opts, [1000], bed, [R.from_records([a, dict(a, pos=50)])])
+    # a failed submit sticks: the job's bookkeeping is half advanced, it cannot go on
+    with snp.PileupJob(opts, [1000]) as job:
+        job.set_bed(bed)
+        job.submit(R.from_records([a]))
+        with pytest.raises(snp.PileupError, match="maxReadLen"):
+            job.submit(R.from_records([dict(a, pos=200), dict(long_read, pos=300)]))
+        for call in (lambda: job.submit(R.from_records([dict(a, pos=400)])), job.finish, job.compute):
+            with pytest.raises(snp.PileupError, match="earlier bp_submit of this job failed .*maxReadLen"):
+                call()
     # stitched overlap with an out-of-range quality: Go panics, we return BP_EDATA
     q = [30] * 5
     p1 = dict(name="p", ref_id=0, pos=100, mapq=60, flags=0x63, mate_pos=102, cigar=[("M", 5)],
@@ -425,20 +434,42 @@ def test_per_read_lists_deep_and_fragmented(case):
         assert len(feats) > 5_000
 
 
-def test_full_size_chr1_30x_properties():
+@pytest.fixture(scope="module")
+def chr1_30x():
+    """BASELINE.json configs[1]: synthetic 30x chr1 (what bench.py times), generated once for
+    the full-size tests of this module (names included: the stitched run keys on them)."""
+    from bench import CHR1_LEN, kept_aligned_bases
+    sb = synth.generate([(0, 0, CHR1_LEN - 1000, 30.0)], threads=16, with_names=True)
+    rb = sb.to_record_batch()
+    B = kept_aligned_bases(rb, dict(flag_exclude=0xF00, mapq=60))
+    yield CHR1_LEN, rb, B
+    sb.close()
+
+
+FULL_WINDOWS = (1_000, 123_456_789, 248_956_422 - 150_000)
+
+
+def _oracle_windows(job, opts, L, rb, pad=600):
+    """Three windows of 100 kb far apart in the contig against the oracle run on just the reads
+    that can reach them (with stitching: and their mates, two spans away)."""
+    for w0 in FULL_WINDOWS:
+        lo = int(np.searchsorted(rb.pos, w0 - pad))
+        hi = int(np.searchsorted(rb.pos, w0 + 100_000 + pad))
+        _, wp, wv = O.pileup(opts, [L], {0: [[w0, w0 + 100_000]]}, rb.slice(lo, hi))
+        _, pos, vals = job.rows(w0, 100_000)
+        assert (pos == wp).all() and (vals == wv).all(), w0
+
+
+def test_full_size_chr1_30x_properties(chr1_30x):
     """BASELINE.json configs[1] at its full size (chr1, 248,956,422 positions, 30x, per-strand
     counts, DefaultOpts; what bench.py times), through properties that do not need the oracle
     at that size: depth = the aligned bases counted on the host, every base in a count slot,
     a second compute gives the same sums, linearity (the rows of two halves of the records add up
     to the rows of all of them, row by row), and three windows of rows far into the contig
     against the oracle run on just the reads that reach them."""
-    from bench import CHR1_LEN, kept_aligned_bases
-    L = CHR1_LEN
-    sb = synth.generate([(0, 0, L - 1000, 30.0)], threads=16)
-    rb = sb.to_record_batch()
+    L, rb, B = chr1_30x
     bed = {0: [[0, L]]}
     opts = O.make_opts()  # DefaultOpts, basestrand semantics (StrandNone dropped)
-    B = kept_aligned_bases(rb, dict(flag_exclude=0xF00, mapq=60))
     with snp.PileupJob(opts, [L]) as job:
         job.set_bed(bed)
         job.submit(rb)
@@ -449,12 +480,7 @@ def test_full_size_chr1_30x_properties():
         assert sum(sums[1:]) == sums[0]
         job.compute()
         assert job.column_sums() == sums
-        for w0 in (1_000, 123_456_789, L - 150_000):
-            lo = int(np.searchsorted(rb.pos, w0 - 600))
-            hi = int(np.searchsorted(rb.pos, w0 + 100_000))
-            _, wp, wv = O.pileup(opts, [L], {0: [[w0, w0 + 100_000]]}, rb.slice(lo, hi))
-            _, pos, vals = job.rows(w0, 100_000)
-            assert (pos == wp).all() and (vals == wv).all(), w0
+        _oracle_windows(job, opts, L, rb)
         # linearity: halves of the records, in two jobs, merged on the device
         half = rb.n // 2
         with snp.PileupJob(opts, [L]) as ja, snp.PileupJob(opts, [L]) as jb:
@@ -470,6 +496,127 @@ def test_full_size_chr1_30x_properties():
             for r0 in range(0, L, step):
                 n = min(step, L - r0)
                 assert (ja.rows(r0, n)[2] == job.rows(r0, n)[2]).all(), r0
+
+
+@pytest.mark.parametrize("mode", ["minq20", "minq20_clip5", "stitch_minq20"])
+def test_full_size_chr1_30x_other_kernel_variants(chr1_30x, mode):
+    """The same contig through the other instantiations of the pileup kernel (quality rule,
+    quality rule + clip, stitched), at full size: Depth counts every aligned base whatever its
+    quality (pileup.go:223-231), so the depth sum is the host's count (stitched: between half of it
+    and all of it, overlaps count once); the count slots can only lose bases against DefaultOpts,
+    column by column; a second compute reproduces the sums; three far-apart windows equal the
+    oracle's rows.  Stitched also holds the reference's own end-to-end property
+    DP_stitched <= DP_unstitched <= 2 DP_stitched, row by row (cmd/bio-pileup/pileup_snp_test.go:85-93)."""
+    L, rb, B = chr1_30x
+    bed = {0: [[0, L]]}
+    kw = dict(minq20=dict(min_base_qual=20), minq20_clip5=dict(min_base_qual=20, clip=5),
+              stitch_minq20=dict(stitch=1, min_base_qual=20))[mode]
+    opts = O.make_opts(**kw)
+    with snp.PileupJob(O.make_opts(), [L]) as base, snp.PileupJob(opts, [L]) as job:
+        for j in (base, job):
+            j.set_bed(bed)
+            j.submit(rb)
+            j.finish()
+        s0, s1 = base.column_sums(), job.column_sums()
+        assert s0[0] == B
+        if kw.get("stitch"):
+            assert B // 2 <= s1[0] < B
+        else:
+            assert s1[0] == B
+        assert sum(s1[1:]) < s1[0]          # some bases fail the quality rule: Depth only
+        assert all(a <= b for a, b in zip(s1[1:9], s0[1:9]))
+        job.compute()
+        assert job.column_sums() == s1
+        _oracle_windows(job, opts, L, rb, pad=1200 if kw.get("stitch") else 600)
+        if kw.get("stitch"):
+            step = 20_000_000
+            for r0 in range(0, L, step):
+                n = min(step, L - r0)
+                d1, d0 = job.rows(r0, n)[2][:, 0], base.rows(r0, n)[2][:, 0]
+                assert (d1 <= d0).all() and (d0 <= 2 * d1).all(), r0
+
+
+def _c4_panel():
+    """BASELINE.json configs[3] (C4): 500 targets x 200 bp on one contig."""
+    rng = random.Random(4)
+    targets, p = [], 10_000
+    for _ in range(500):
+        targets.append([p, p + 200])
+        p += 200 + rng.randint(300, 3000)
+    return targets, p + 10_000
+
+
+def test_full_size_c4_deep_panel_stitched():
+    """BASELINE config 4 at its stated size: 500 targets x 200 bp at ~10,000x, 2x150 mates with
+    insert ~N(170,20) so that every pair overlaps, -stitch -min-base-qual 20 -mapq 60 (16.7 M
+    records, every window deep: the sliced second launch with its plane copies does all the
+    work).  Properties over the whole panel (depth between half and all of the kept aligned bases,
+    a second compute reproduces the sums, stitched depth against the unstitched rows as in
+    pileup_snp_test.go:85-93) and the oracle's rows on 12 whole targets (first, middle, last 4)."""
+    from bench import kept_aligned_bases
+    targets, L = _c4_panel()
+    bed = {0: targets}
+    sb = synth.generate([(0, s, e, 10000.0) for s, e in targets], with_names=True, threads=16,
+                        insert_mean=170.0, insert_sd=20.0, insert_min=100, insert_max=300)
+    rb = sb.to_record_batch()
+    assert rb.n > 15_000_000
+    opts = O.make_opts(stitch=1, min_base_qual=20, mapq=60)
+    with snp.PileupJob(O.make_opts(mapq=60), [L]) as base, snp.PileupJob(opts, [L]) as job:
+        for j in (base, job):
+            j.set_bed(bed)
+            j.submit(rb)
+            j.finish()
+        assert job.num_rows == 500 * 200
+        s0, s1 = base.column_sums(), job.column_sums()
+        assert s0[0] > 500 * 200 * 5000
+        assert s0[0] // 2 <= s1[0] < s0[0]
+        job.compute()
+        assert job.column_sums() == s1
+        _, pos, v1 = job.rows()
+        v0 = base.rows()[2]
+        assert (v1[:, 0] <= v0[:, 0]).all() and (v0[:, 0] <= 2 * v1[:, 0]).all()
+        assert v1[:, 0].min() > 2000
+        for t0 in (0, 248, 496):
+            sub = targets[t0:t0 + 4]
+            lo = int(np.searchsorted(rb.pos, sub[0][0] - 1200))
+            hi = int(np.searchsorted(rb.pos, sub[-1][1] + 1200))
+            _, wp, wv = O.pileup(opts, [L], {0: sub}, rb.slice(lo, hi))
+            r0 = 200 * t0
+            assert (pos[r0:r0 + 800] == wp).all() and (v1[r0:r0 + 800] == wv).all(), t0
+    sb.close()
+
+
+def test_full_size_c5_60x_chr1_per_read_lists():
+    """BASELINE config 5 at its size on one GPU: chr1 at 60x with the ordered per-read lists of
+    -cols dpref,quals (appendBase, pileup.go:235-250; 99.6 M records, ~12 G list entries, ~120 GB
+    resident).  Over everything: the list offsets end at the sum of the A,C,G,T counts (a list's
+    length is its count), and the build checks on the device that every list ends where the scan
+    put it.  Lists of three 100 kb windows against the oracle's, entry for entry.  (PAM input, the
+    other half of config 5, is not built: INTEGRATION.md.)"""
+    from bench import CHR1_LEN
+    L = CHR1_LEN
+    sb = synth.generate([(0, 0, L - 1000, 60.0)], threads=16)
+    rb = sb.to_record_batch()
+    opts = O.make_opts(min_base_qual=13)
+    with snp.PileupJob(opts, [L]) as job:
+        job.set_bed({0: [[0, L]]})
+        job.submit(rb)
+        job.finish()
+        sums = job.column_sums()
+        job._check(job.lib.bp_per_read_build(job.h))
+        n_feat = int(job.lib.bp_per_read_total(job.h))
+        assert n_feat == sum(sums[1:9]) and n_feat > 10_000_000_000
+        off_end = np.zeros(5, np.uint64)
+        job._check(job.lib.bp_per_read_offsets(job.h, L - 1, 1, off_end.ctypes.data_as(C.POINTER(C.c_uint64))))
+        assert int(off_end[-1]) == n_feat
+        for w0 in FULL_WINDOWS:
+            lo = int(np.searchsorted(rb.pos, w0 - 600))
+            hi = int(np.searchsorted(rb.pos, w0 + 100_000))
+            _, wp, wv, woff, wfeat = O.pileup_per_read(opts, [L], {0: [[w0, w0 + 100_000]]}, rb.slice(lo, hi))
+            _, pos, vals = job.rows(w0, 100_000)
+            assert (pos == wp).all() and (vals == wv).all(), w0
+            off, feats = job.per_read(w0, 100_000)
+            assert (off == woff).all() and feats.tobytes() == wfeat.tobytes(), w0
     sb.close()
 
 
@@ -540,3 +687,55 @@ def test_rows_to_text_on_device():
                 job.render_text(*other)
         with pytest.raises(snp.PileupError, match="per-read columns"):
             job.render_text(n0, 5, 1, 8)
+
+
+def _qual_pair_batch():
+    """96 x 96 two-read pairs, one per (i, j): 4M reads at P and P+3 that agree on the one position
+    they share, where the stored read has quality i and the read that finds it quality j."""
+    n_pair = 96 * 96
+    n = 2 * n_pair
+    k = np.arange(n_pair)
+    P = 16 * k + 8
+    first = np.arange(n) % 2 == 0
+    pos = np.where(first, np.repeat(P, 2), np.repeat(P, 2) + 3).astype(np.int32)
+    mate_pos = np.where(first, np.repeat(P, 2) + 3, np.repeat(P, 2)).astype(np.int32)
+    qual = np.full((n, 4), 30, np.uint8)
+    qual[0::2, 3] = k // 96   # i: last base of the stored read
+    qual[1::2, 0] = k % 96    # j: first base of its mate
+    names = np.frombuffer("".join("p%05d" % (x // 2) for x in range(n)).encode(), np.uint8)
+    return R.RecordBatch(
+        ref_id=np.zeros(n, np.int32), pos=pos, mate_ref_id=np.zeros(n, np.int32), mate_pos=mate_pos,
+        flags=np.where(first, 0x63, 0x93).astype(np.uint16), mapq=np.full(n, 60, np.uint8),
+        n_cigar=np.ones(n, np.uint32), l_seq=np.full(n, 4, np.uint32), cigar_off=np.arange(n, dtype=np.uint64),
+        cigar=np.full(n, (4 << 4) | 0, np.uint32), seq_off=2 * np.arange(n, dtype=np.uint64),
+        seq=np.full(2 * n, 0x11, np.uint8), qual_off=4 * np.arange(n, dtype=np.uint64), qual=qual.reshape(-1),
+        name_off=6 * np.arange(n + 1, dtype=np.uint64), name=names), P
+
+
+def test_qual_sum_table_exhaustive_through_the_device():
+    """qualSumTable / qualPassTable (pileup/snp/qual.go:35-81) through the stitched device path,
+    every (minBaseQual, q0, q1): the kernel works from a per-row threshold the library derives
+    with its own copy of the formula, so a wrong entry anywhere would show here.  The oracle's
+    table is the float64 restatement pinned by qual_internal_test.go:46-54."""
+    batch, P = _qual_pair_batch()
+    L = int(P[-1]) + 32
+    bed = {0: [[0, L]]}
+    n_pass_prev = None
+    for minq in range(1, 96):
+        opts = O.make_opts(stitch=1, min_base_qual=minq)
+        want = O.pileup(opts, [L], bed, batch)
+        got = device_rows(opts, [L], bed, [batch])
+        assert_same(got, want, f"minBaseQual {minq}")
+        # the shared position of pair (i, j) holds A+ = 1 iff qualSum[i][j] >= minBaseQual
+        a_plus = got[2][P + 3, 1]
+        depth = got[2][P + 3, 0]
+        assert (depth == 1).all()
+        lib = O.load()
+        tab = np.array([[lib.orc_qual_pass(minq, i, j) for j in range(96)] for i in range(96)], np.uint32) \
+            if minq in (1, 20, 43, 95) else None
+        if tab is not None:
+            assert (a_plus.reshape(96, 96) == tab).all(), minq
+        n_pass = int(a_plus.sum())
+        assert n_pass_prev is None or n_pass <= n_pass_prev  # raising the bar never passes more pairs
+        n_pass_prev = n_pass
+    assert 0 < n_pass_prev < 96 * 96

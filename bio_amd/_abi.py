@@ -63,7 +63,7 @@ class bp_timing(C.Structure):
 
 
 EXPORTS = [
-    "bp_init", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute",
+    "bp_init", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute", "bp_compute_static",
     "bp_num_rows", "bp_rows", "bp_rows_device", "bp_rows_export", "bp_rows_accumulate", "bp_rows_export_async", "bp_rows_accumulate_async", "bp_stream", "bp_column_sums", "bp_get_timing",
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
@@ -141,6 +141,8 @@ def load():
     lib.bp_rows_device.restype = C.c_int
     lib.bp_rows_export.argtypes = [H, C.c_int64, C.c_int64, C.c_void_p]
     lib.bp_rows_export.restype = C.c_int
+    lib.bp_compute_static.argtypes = [H]
+    lib.bp_compute_static.restype = C.c_int
     lib.bp_rows_accumulate.argtypes = [H, C.c_int64, C.c_int64, C.c_void_p]
     lib.bp_rows_accumulate.restype = C.c_int
     lib.bp_rows_export_async.argtypes = [H, C.c_int64, C.c_int64, C.c_void_p]

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,6 +41,25 @@ void launch_text_write(const TextParams& T, hipStream_t s);
 }  // namespace bp
 
 using namespace bp;
+
+// ---- scratch of the allocation-free compute (bp_compute_static; no counterpart in the reference).
+// What bp_compute keeps in buffers it allocates (the plan kernel's record range per window, the
+// work-item queue of deep windows with its counter, the device error flags) lives here in a
+// file-scope device array instead, one copy per GPU, held until the process ends:
+//   [0, 256)            n_extra, the queue's item counter
+//   [256, 512)          DeviceError
+//   [512, +4 maxW)      win_r0        [+4 maxW)  win_r1        [+16 maxItems)  extra_items
+// In host code the array's NAME is only a stand-in: its device address is looked up once per
+// device with hipGetSymbolAddress (bp_init, that device current) and kept in g_scratch_ptr; host
+// code uses that pointer, never the name, wherever it needs the memory.
+constexpr int64_t kStaticMaxWindows = 1 << 19;  // 536,870,912 window positions
+constexpr int64_t kStaticMaxItems = 1 << 18;
+constexpr size_t kStaticCounterOff = 0, kStaticErrOff = 256, kStaticR0Off = 512;
+constexpr size_t kStaticR1Off = kStaticR0Off + 4 * (size_t)kStaticMaxWindows;
+constexpr size_t kStaticItemsOff = kStaticR1Off + 4 * (size_t)kStaticMaxWindows;
+constexpr size_t kStaticBytes = kStaticItemsOff + 16 * (size_t)kStaticMaxItems;  // 8 MiB + 512 B
+static_assert(kStaticItemsOff % 16 == 0, "work items are uint4");
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 namespace {
 
@@ -128,6 +148,8 @@ struct bp_handle {
   int cur_stage = 0;
   bp_timing timing{};
   bool rows_valid = false;
+  bool resident = false;            // a bp_finish has run: every table the kernels read is on the device
+  DeviceError* host_err = nullptr;  // pinned word the allocation-free compute reads its error flags into
 };
 
 namespace {
@@ -487,6 +509,24 @@ int acquire_stage(bp_handle* h, Staging** out) {
   return 0;
 }
 
+constexpr int kMaxDevices = 64;
+uint8_t* g_scratch_ptr[kMaxDevices];  // per device: where that GPU's copy of `scratch` lives
+std::mutex g_scratch_mu;
+
+// Called with `device` current.
+int resolve_scratch(int device) {
+  if (device < 0 || device >= kMaxDevices) return BP_OK;  // bp_compute_static refuses such a device
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[device]) return BP_OK;
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !p)
+    return fail(nullptr, BP_EDEVICE, "bp_init: hipGetSymbolAddress(scratch) on device %d: %s", device,
+                e != hipSuccess ? hipGetErrorString(e) : "null address");
+  g_scratch_ptr[device] = (uint8_t*)p;
+  return BP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -500,7 +540,7 @@ int bp_init(int32_t device) {
   if (device < 0 || device >= n) return fail(nullptr, BP_EINVAL, "bp_init: device %d of %d", device, n);
   e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, BP_EDEVICE, "hipSetDevice: %s", hipGetErrorString(e));
-  return BP_OK;
+  return resolve_scratch(device);
 }
 
 int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const char* const* ref_name,
@@ -530,7 +570,7 @@ int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const 
   if (int rc = build_qthr(h)) { delete h; return rc; }
   auto bail = [&](const char* what, hipError_t e) {
     int rc = fail(nullptr, BP_EDEVICE, "%s: %s", what, hipGetErrorString(e));
-    delete h;
+    bp_destroy(h);
     return rc;
   };
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -539,6 +579,8 @@ int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const 
     e = hipEventCreate(&h->ev[i]);
     if (e != hipSuccess) return bail("hipEventCreate", e);
   }
+  e = hipHostMalloc((void**)&h->host_err, 256, hipHostMallocDefault);
+  if (e != hipSuccess) return bail("hipHostMalloc", e);
   *out = h;
   return BP_OK;
 }
@@ -743,6 +785,36 @@ static void fill_params(bp_handle* h, KernelParams& P) {
   P.strand_req = h->o.strand_req;
 }
 
+// Plan + pileup kernels over the resident job with the kernel arguments P (whose scratch
+// pointers the caller chose), timed with the handle's events; the device error flags come back
+// through `got` (host memory the copy may target: pinned for the allocation-free path).
+static int run_kernels(bp_handle* h, const KernelParams& P, DeviceError* got) {
+  HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+  launch_plan(P, (int32_t*)P.win_r0, (int32_t*)P.win_r1, h->stream);
+  HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+  launch_pileup(P, h->stream);
+  HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(got, P.err, sizeof(*got), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->timing = bp_timing{};
+  (void)hipEventElapsedTime(&h->timing.plan_ms, h->ev[0], h->ev[1]);
+  (void)hipEventElapsedTime(&h->timing.pileup_ms, h->ev[1], h->ev[2]);
+  (void)hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[2]);
+  h->timing.n_windows = (int64_t)h->windows.size();
+  h->timing.n_items = (int64_t)h->windows.size();
+  h->rows_valid = false;
+  if (got->kind == ERR_ITEM_OVERFLOW)
+    return fail(h, BP_EDEVICE, "bp_compute: work-item list of deep windows overflowed");
+  if (got->read != 0x7fffffff)
+    return fail(h, BP_EDATA,
+                "qualPassTable.lookup2: base quality >= 96 in a stitched overlap (record %d); the "
+                "reference panics with index out of range (qual.go:26,79-81)", got->read);
+  h->rows_valid = true;
+  h->per_read_valid = false;
+  return BP_OK;
+}
+
 int bp_compute(bp_handle* h) {
   if (!h) return fail(h, BP_EINVAL, "bp_compute: null handle");
   if (h->poison_code) return fail(h, h->poison_code, "%s", h->poison_msg.c_str());
@@ -784,30 +856,50 @@ int bp_compute(bp_handle* h) {
   HIP_TRY(h, hipMemsetAsync(h->d_dbg.p, 0, h->windows.size() * 8 * (8 * 8 + 8 * 4), h->stream));
   P.dbg = (unsigned long long*)h->d_dbg.p;
 #endif
-  HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
-  launch_plan(P, (int32_t*)h->d_r0.p, (int32_t*)h->d_r1.p, h->stream);
-  HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-  launch_pileup(P, h->stream);
-  HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
-  HIP_TRY(h, hipGetLastError());
   DeviceError got{};
-  HIP_TRY(h, hipMemcpyAsync(&got, h->d_err.p, sizeof(got), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  h->timing = bp_timing{};
-  (void)hipEventElapsedTime(&h->timing.plan_ms, h->ev[0], h->ev[1]);
-  (void)hipEventElapsedTime(&h->timing.pileup_ms, h->ev[1], h->ev[2]);
-  (void)hipEventElapsedTime(&h->timing.total_ms, h->ev[0], h->ev[2]);
-  h->timing.n_windows = (int64_t)h->windows.size();
-  h->timing.n_items = (int64_t)h->windows.size();
-  if (got.kind == ERR_ITEM_OVERFLOW)
-    return fail(h, BP_EDEVICE, "bp_compute: work-item list of deep windows overflowed");
-  if (got.read != 0x7fffffff)
-    return fail(h, BP_EDATA,
-                "qualPassTable.lookup2: base quality >= 96 in a stitched overlap (record %d); the "
-                "reference panics with index out of range (qual.go:26,79-81)", got.read);
-  h->rows_valid = true;
-  h->per_read_valid = false;
+  if (int rc = run_kernels(h, P, &got)) return rc;
+  h->resident = h->finished;
   return BP_OK;
+}
+
+// bp_compute for callers that cannot allocate: the same kernels over the same resident records
+// and BED, writing the same rows, with their scratch in this GPU's copy of the file-scope
+// `scratch` array (through g_scratch_ptr, never the array's name) instead of buffers of the
+// handle.  No hipMalloc / hipFree / allocating routine from here on: the tables the kernels read
+// were uploaded by the bp_finish that must have run, the error flags come back into the pinned
+// word bp_create allocated, and the counters that must start at zero are cleared with memsets on
+// the job's stream.  The array keeps whatever the last call on this GPU left in it.
+int bp_compute_static(bp_handle* h) {
+  if (!h) return fail(h, BP_EINVAL, "bp_compute_static: null handle");
+  if (h->poison_code) return fail(h, h->poison_code, "%s", h->poison_msg.c_str());
+  if (!h->resident)
+    return fail(h, BP_EINVAL, "bp_compute_static: call bp_finish first (it uploads what the kernels read; "
+                              "this call allocates and uploads nothing)");
+  if (h->device < 0 || h->device >= kMaxDevices || !g_scratch_ptr[h->device])
+    return fail(h, BP_EINVAL, "bp_compute_static: no scratch address for device %d", h->device);
+  const int64_t n_win = (int64_t)h->windows.size(), n_items = item_capacity(h);
+  if (n_win > kStaticMaxWindows)
+    return fail(h, BP_EINVAL, "bp_compute_static: %lld windows of %d positions; the static scratch holds %lld "
+                              "(use bp_compute, or cut the job)", (long long)n_win, window_size(), (long long)kStaticMaxWindows);
+  if (n_items > kStaticMaxItems)
+    return fail(h, BP_EINVAL, "bp_compute_static: up to %lld work items of deep windows (%lld records); the static "
+                              "scratch holds %lld (use bp_compute, or cut the job)", (long long)n_items,
+                (long long)h->n_reads, (long long)kStaticMaxItems);
+  HIP_TRY(h, hipSetDevice(h->device));
+  uint8_t* const sp = g_scratch_ptr[h->device];
+  KernelParams P{};
+  fill_params(h, P);
+  P.win_r0 = (const int32_t*)(sp + kStaticR0Off);
+  P.win_r1 = (const int32_t*)(sp + kStaticR1Off);
+  P.n_extra = (uint32_t*)(sp + kStaticCounterOff);
+  P.extra_items = (uint4*)(sp + kStaticItemsOff);
+  P.extra_cap = (int32_t)n_items;
+  P.err = (DeviceError*)(sp + kStaticErrOff);
+  // what must start at zero: the item counter; and the error flags at "none"
+  HIP_TRY(h, hipMemsetAsync(sp + kStaticCounterOff, 0, 256, h->stream));
+  HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(sp + kStaticErrOff), 0x7fffffff, 1, h->stream));
+  HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(sp + kStaticErrOff + 4), (int)ERR_NONE, 1, h->stream));
+  return run_kernels(h, P, h->host_err);
 }
 
 int bp_finish(bp_handle* h) {
@@ -1166,6 +1258,7 @@ void bp_destroy(bp_handle* h) {
   }
   for (hipEvent_t e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->host_err) (void)hipHostFree(h->host_err);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

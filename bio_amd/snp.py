@@ -107,6 +107,10 @@ class PileupJob:
     def compute(self):
         self._check(self.lib.bp_compute(self.h))
 
+    def compute_static(self):
+        """compute() with the kernels' scratch in the library's static device array: allocates nothing"""
+        self._check(self.lib.bp_compute_static(self.h))
+
     @property
     def num_rows(self):
         return int(self.lib.bp_num_rows(self.h))

@@ -138,6 +138,20 @@ int bp_finish(bp_handle* h);
  * for measurement and for callers that change nothing but want fresh rows. */
 int bp_compute(bp_handle* h);
 
+/* bp_compute for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it exists for those
+ * callers only.  Runs the same kernels as bp_compute over the same resident records and BED and
+ * writes the same rows, but keeps the kernels' scratch (the plan's record range per window, the
+ * work-item queue of deep windows and its counter, the device error flags) in a static device
+ * array of 8 MiB + 512 B that every GPU the library runs on holds until the process ends, and
+ * calls no hipMalloc / hipFree / allocating routine.  A bp_finish must have run on the handle
+ * (it uploads what the kernels read).  Limits, refused with BP_EINVAL: 524,288 windows of 1,024
+ * positions (536,870,912 window positions) and 262,144 work items of deep windows (a job can
+ * have up to records / 512 + 18 of them with spans below 1,024: about 134 M records).  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (two handles, two threads) race; calls one after
+ * the other are independent, whatever the earlier one left behind. */
+int bp_compute_static(bp_handle* h);
+
 /* Number of rows = number of BED positions of the job (one PileupRow per position,
  * zero-depth ones included: pileup.go:518-570, pileup_support.go:89-123). */
 int64_t bp_num_rows(const bp_handle* h);

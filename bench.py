@@ -2,18 +2,32 @@
 """bench.py -- aligned bases piled up per second on MI355X (BASELINE.json metric).
 
 A step = one pass of the pileup hot path (window planning + count/flush kernels, i.e.
-bp_compute) over one resident batch of synthetic coordinate-sorted records.
+bp_compute; with per-read lists also their scan + gather, bp_per_read_build) over one resident
+batch of synthetic coordinate-sorted records.
 
-Workload at N=1 (BASELINE.json configs[1]): synthetic 30x chr1 (248,956,422 bp), 2x150 FR
-pairs with the SURVEY.md section 8(d) CIGAR/flag/MAPQ mix, BED = whole contig, basestrand
-semantics (per-strand counts in one pass).  With --gpus N every rank processes its own
-chr1-sized contig (independent genomic partitions, no data-path collective): weak scaling.
+--config selects the workload (BASELINE.json configs):
+  c2   (default, BASELINE configs[1]) synthetic 30x chr1 (248,956,422 bp), 2x150 FR pairs with
+       the section 8(d) CIGAR/flag/MAPQ mix, BED = whole contig, basestrand (per-strand counts in
+       one pass), DefaultOpts
+  c2q  the same records, -min-base-qual 20            (quality-rule kernel variant)
+  c2c  the same records, -min-base-qual 20 -clip 5    (clip variant)
+  c2s  the same records, -stitch -min-base-qual 20    (stitched variant)
+  c4   (configs[3]) 500 targets x 200 bp at ~10,000x, 2x150 mates with insert ~N(170,20),
+       -stitch -min-base-qual 20 -mapq 60
+  c5   (configs[4] on one GPU) chr1 at 60x with the ordered per-read lists of -cols dpref,quals
+  c3   (configs[2]) 24 contigs with hg38's lengths (3.1 Gb) at 30x cut into N position ranges, one
+       per rank, reads partitioned by start, boundary rows merged over RCCL; needs --gpus >= 4
+       (or BENCH_EMULATE_RANK=g/N to run one rank's share on a one-GPU box)
+With --gpus N (c2 only besides c3) every rank owns a chr1-sized range of ONE contig of N x chr1
+positions: weak scaling, reads partitioned by start, boundary merge per step.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
+import random
 import sys
 import time
 
@@ -23,29 +37,109 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CHR1_LEN = 248_956_422
+# hg38 primary assembly, chr1..chr22, chrX, chrY (the contig lengths of BASELINE config 3)
+HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+             138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+             83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # secondary ceiling: the kernel issues one ds_add_u32 per aligned base;
 # a wave's ds_add_u32 (64 lanes x address + data) occupies a CU's LDS for 4 cycles = 16 lane
 # atomics per cycle and CU, x 256 CUs x 2.4 GHz
 LDS_ATOMIC_PEAK_G = 16 * 256 * 2.4
 
+CONFIGS = {
+    "c2": dict(opts={}, coverage=30.0, what="DefaultOpts"),
+    "c2q": dict(opts=dict(MinBaseQual=20), coverage=30.0, what="-min-base-qual 20"),
+    "c2c": dict(opts=dict(MinBaseQual=20, Clip=5), coverage=30.0, what="-min-base-qual 20 -clip 5"),
+    "c2s": dict(opts=dict(MinBaseQual=20, Stitch=True), coverage=30.0, what="-stitch -min-base-qual 20"),
+    "c4": dict(opts=dict(MinBaseQual=20, Stitch=True, Mapq=60), coverage=10000.0, what="-stitch -min-base-qual 20 -mapq 60"),
+    "c5": dict(opts=dict(MinBaseQual=13), coverage=60.0, per_read=True, what="-min-base-qual 13 -cols dpref,quals"),
+    "c3": dict(opts={}, coverage=30.0, what="DefaultOpts"),
+}
 
-def kept_aligned_bases(rb, opts_kw):
-    """B of SURVEY.md section 8(d), counted on the host from the generated records:
-    CIGAR-M bases of records passing the read-level filters (all of them lie on the BED)."""
+
+def keep_mask(rb, flag_exclude=0xF00, mapq=60):
+    """Records passing the read-level filters of processShard (pileup.go:691, :717-729) in a
+    basestrand run (StrandNone dropped, pileup.go:724-729)."""
     flags = rb.flags.astype(np.uint32)
-    keep = ((flags & opts_kw["flag_exclude"]) == 0) & (rb.mapq >= opts_kw["mapq"]) & (rb.n_cigar > 0)
+    keep = ((flags & flag_exclude) == 0) & (rb.mapq >= mapq) & (rb.n_cigar > 0)
     f = flags & 0xF0
     same = rb.ref_id == rb.mate_ref_id
     fwd = same & ((f == 0x60) | (f == 0x90) | (((flags & 8) != 0) & ((f & 0x30) == 0)))
     rev = same & ((f == 0x50) | (f == 0xA0) | (((flags & 8) != 0) & ((f & 0x30) == 0x30)))
-    keep &= fwd | rev  # basestrand formats drop StrandNone (pileup.go:724-729)
-    ops = rb.cigar & 15
-    mlen = np.where(ops == 0, rb.cigar >> 4, 0).astype(np.int64)
-    csum = np.concatenate([[0], np.cumsum(mlen)])
+    return keep & (fwd | rev)
+
+
+def kept_aligned_bases(rb, opts_kw, bed=None):
+    """B of SURVEY.md section 8(d), counted on the host from the generated records: CIGAR-M
+    bases of records passing the read-level filters that lie on a BED position (bed = sorted
+    [[start, end), ...] of the records' one contig; None: every position is a BED position)."""
+    keep = keep_mask(rb, opts_kw["flag_exclude"], opts_kw["mapq"])
     off = rb.cigar_off.astype(np.int64)
-    per_read = csum[off + rb.n_cigar.astype(np.int64)] - csum[off]
-    return int(per_read[keep].sum())
+    nc = rb.n_cigar.astype(np.int64)
+    # the ops of the batch's records, flattened (a sliced batch still points into its parent's arrays)
+    first = np.cumsum(nc) - nc
+    read_of_op = np.repeat(np.arange(rb.n), nc)
+    cig = rb.cigar[np.repeat(off - first, nc) + np.arange(int(nc.sum()))]
+    ops = cig & 15
+    lens = (cig >> 4).astype(np.int64)
+    if bed is None:
+        mlen = np.where(ops == 0, lens, 0)
+        csum = np.concatenate([[0], np.cumsum(mlen)])
+        per_read = csum[first + nc] - csum[first]
+        return int(per_read[keep].sum())
+    # reference position of every op: pos of its read + reference bases consumed before it
+    rcons = np.where((ops == 0) | (ops == 2) | (ops == 3), lens, 0)
+    rsum = np.concatenate([[0], np.cumsum(rcons)])
+    op_start = rb.pos.astype(np.int64)[read_of_op] + (rsum[:-1] - rsum[first][read_of_op])
+    sel = (ops == 0) & keep[read_of_op]
+    s, e = op_start[sel], op_start[sel] + lens[sel]
+    ep = np.asarray(bed, np.int64).reshape(-1)
+    cum = np.concatenate([[0], np.cumsum(ep[1::2] - ep[0::2])])  # BED positions before interval k
+
+    def cov(x):  # BED positions < x
+        k = np.searchsorted(ep, x, "right")
+        inside = (k & 1) == 1
+        return cum[k // 2] + np.where(inside, x - ep[np.maximum(k - 1, 0)], 0)
+    return int((cov(e) - cov(s)).sum())
+
+
+def c4_panel():
+    """BASELINE.json configs[3]: 500 targets x 200 bp on one contig (seeded)."""
+    rng = random.Random(4)
+    targets, p = [], 10_000
+    for _ in range(500):
+        targets.append([p, p + 200])
+        p += 200 + rng.randint(300, 3000)
+    return targets, p + 10_000
+
+
+def kernel_source_hash():
+    """What a committed traffic measurement is valid for: the kernels' source text."""
+    h = hashlib.sha256()
+    for f in ("pileup_kernels.hip", "pileup_device.h"):
+        h.update(open(os.path.join(ROOT, "bio_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(cfg, kernel):
+    """HBM traffic is not measurable inside this process (PMC counters need their own rocprofv3
+    passes): report the committed measurement of the same config and kernel if it was taken on
+    these very kernel sources, else null."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", f"traffic_{cfg}.json")))
+        if tj["kernel_source_sha256"] == kernel_source_hash() and tj["kernel"] in kernel:
+            return tj["traffic_bytes_per_launch"], f"profiles/traffic_{cfg}.json ({tj['source']})"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def c3_share(rank, world):
+    """Position ranges of rank `rank` when the 24 contigs are cut into `world` runs of equal size."""
+    from bio_amd import partition
+    bed = {r: [[0, l]] for r, l in enumerate(HG38_LENS)}
+    return partition.plan_partitions(bed, world)[rank]
 
 
 def main():
@@ -53,23 +147,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--length", type=int, default=CHR1_LEN, help="contig length (default chr1)")
-    ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--cpu-sample-mb", type=float, default=200.0,
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--length", type=int, default=CHR1_LEN, help="contig length of the c2*/c5 configs (default chr1)")
+    ap.add_argument("--coverage", type=float, default=None)
+    ap.add_argument("--cpu-sample-mb", type=float, default=None,
                     help="genomic megabases of the workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    cname = args.config
+    coverage = args.coverage if args.coverage is not None else cfg["coverage"]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    emulate = os.environ.get("BENCH_EMULATE_RANK")
+    if world != args.gpus and not (emulate and world == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with torch.distributed.run "
+                         f"(one rank per GPU), or set BENCH_EMULATE_RANK=g/N to run one rank's share alone")
+    if world > 1 and cname not in ("c2", "c3"):
+        raise SystemExit(f"--config {cname} is a one-GPU workload")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pileup path has no CPU fallback")
     # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
-    # multi-rank flow on a single-GPU box (the ranks' only traffic is two scalar reductions)
+    # multi-rank flow on a single-GPU box
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
@@ -82,41 +184,85 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from bio_amd import _abi, snp, synth
+    from bio_amd import partition, snp, synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
 
     L = args.length
-    opts_kw = dict(flag_exclude=0xF00, mapq=60)
-    o = snp.Opts()  # DefaultOpts
+    o = snp.Opts(**cfg["opts"])
+    opts_kw = dict(flag_exclude=o.FlagExclude, mapq=o.Mapq)
     bopts = snp.device_opts(o, "basestrand-tsv", device=dev_index)
+    per_read = bool(cfg.get("per_read"))
 
     t0 = time.time()
     threads = min(16, os.cpu_count() or 1)
-    from bio_amd import partition
-    # N > 1: ONE contig of N x L positions cut into N position ranges (weak scaling: every
-    # rank owns L positions at the same coverage).  Reads are partitioned, not replicated:
-    # rank g gets the reads that start in its range, so what they contribute behind its end
-    # lands in `tail` extra rows that go to rank g+1 after the kernels (the boundary merge of
-    # BASELINE config 3; the only data-path communication, one small all-gather per step).
-    # (BENCH_EMULATE_RANK=g/N: this single process takes the place of rank g of N, without the
-    # exchange, to check one shard of a large run on a one-GPU box)
     prank, pworld = rank, world
-    if world == 1 and os.environ.get("BENCH_EMULATE_RANK"):
-        prank, pworld = (int(x) for x in os.environ["BENCH_EMULATE_RANK"].split("/"))
+    if world == 1 and emulate:
+        prank, pworld = (int(x) for x in emulate.split("/"))
     tail = 1024 if pworld > 1 else 0
-    total_len = L * pworld
-    start, end, bed_end = partition.boundary_ranges(total_len, pworld, prank, tail)
-    gen_end = end if prank + 1 < pworld else end - 1000
-    sb = synth.generate([(0, start, gen_end, args.coverage)], seed=synth.SEED + prank, threads=threads)
+    bed_list = None  # BED intervals when they are not the whole range (c4)
+    gen_kw = {}
+    if cname == "c4":
+        targets, total_len = c4_panel()
+        regions = [(0, s, e, coverage) for s, e in targets]
+        bed = {0: targets}
+        bed_list = targets
+        ref_lens, ref_names = [total_len], ["chr1"]
+        gen_kw = dict(insert_mean=170.0, insert_sd=20.0, insert_min=100, insert_max=300)
+        own_rows, tail_rows = 500 * 200, 0
+        workload = (f"synthetic deep panel: 500 targets x 200 bp at ~{coverage:g}x, 2x150 mates with insert ~N(170,20) "
+                    f"(every pair overlaps), {cfg['what']}, basestrand counts")
+    elif cname == "c3":
+        # The genome's positions are cut into pworld runs; a run may span contigs.  Reads are
+        # partitioned by start: behind the END of a rank's last range its reads spill into `tail`
+        # rows that belong to the next rank (when that rank continues the same contig).
+        if pworld < 4:
+            raise SystemExit("--config c3 (3.1 Gb at 30x) needs --gpus >= 4: a rank's share must fit one GPU and one job's 32 GiB of payload")
+        share = c3_share(prank, pworld)
+        nxt = c3_share(prank + 1, pworld)[0] if prank + 1 < pworld else None
+        last_ref, _, last_end = share[-1]
+        spill = nxt is not None and nxt[0] == last_ref  # the next rank continues this contig
+        regions = [(r, s, (e if (r, e) == (last_ref, last_end) and spill else e - 1000), coverage) for r, s, e in share]
+        bed = {}
+        for r, s, e in share:
+            bed.setdefault(r, []).append([s, e])
+        tail_rows = 0
+        if spill:
+            tail_rows = min(tail, HG38_LENS[last_ref] - last_end)
+            bed[last_ref][-1][1] = last_end + tail_rows
+        own_rows = sum(e - s for _, s, e in share)
+        ref_lens = list(HG38_LENS)
+        ref_names = [f"chr{i + 1}" for i in range(22)] + ["chrX", "chrY"]
+        total_len = sum(HG38_LENS)
+        workload = (f"synthetic {coverage:g}x whole genome: 24 contigs with hg38's lengths ({total_len} bp) cut into "
+                    f"{pworld} position ranges, 2x150 FR pairs, basestrand counts, DefaultOpts")
+    else:
+        # N > 1: ONE contig of N x L positions cut into N position ranges (weak scaling: every
+        # rank owns L positions at the same coverage).  Reads are partitioned, not replicated:
+        # rank g gets the reads that start in its range, so what they contribute behind its end
+        # lands in `tail` extra rows that go to rank g+1 after the kernels (the boundary merge of
+        # BASELINE config 3; the only data-path communication, one small all-gather per step).
+        total_len = L * pworld
+        start, end, bed_end = partition.boundary_ranges(total_len, pworld, prank, tail)
+        gen_end = end if prank + 1 < pworld else end - 1000
+        regions = [(0, start, gen_end, coverage)]
+        bed = {0: [[start, bed_end]]}
+        ref_lens, ref_names = [total_len], ["chr1"]
+        own_rows, tail_rows = end - start, bed_end - end
+        workload = (f"synthetic {coverage:g}x chr1-sized contig ({L} bp) per GPU, 2x150 FR pairs, BED = whole contig, "
+                    f"basestrand (per-strand) counts, {cfg['what']}")
+    sb = synth.generate(regions, seed=synth.SEED + prank, threads=threads, with_names=bool(o.Stitch), **gen_kw)
     rb = sb.to_record_batch()
-    if start > 0:  # the generator also starts pairs a little before its region: not ours
-        rb = rb.slice(int(np.searchsorted(rb.pos, start, "left")), rb.n)
+    if cname in ("c2", "c3") and pworld > 1:
+        # the generator also starts pairs a little before a region: those belong to the left neighbour
+        r0, s0 = regions[0][0], regions[0][1]
+        if s0 > 0:
+            key = rb.ref_id.astype(np.int64) << 32 | rb.pos.astype(np.int64)
+            rb = rb.slice(int(np.searchsorted(key, (r0 << 32) | s0, "left")), rb.n)
     gen_s = time.time() - t0
-    B = kept_aligned_bases(rb, opts_kw)
-    own_rows, tail_rows = end - start, bed_end - end
+    B = kept_aligned_bases(rb, opts_kw, bed_list)
 
-    job = snp.PileupJob(bopts, [total_len], ["chr1"])
-    job.set_bed({0: [[start, bed_end]]})
+    job = snp.PileupJob(bopts, ref_lens, ref_names)
+    job.set_bed(bed)
     job.reserve(rb.n, len(rb.cigar) * 4 + len(rb.seq) + len(rb.qual))
     t0 = time.time()
     job.submit(rb)
@@ -128,33 +274,39 @@ def main():
 
     def step():
         job.compute()
+        if per_read:
+            job._check(job.lib.bp_per_read_build(job.h))
         if dist is not None:
             partition.exchange_boundaries(dist, torch, job, own_rows, tail_rows, tail, rank, world, device=wire)
 
+    t0 = time.time()
+    job.finish()
+    finish_s = time.time() - t0  # stitched runs: includes the upload of the mate table
     for _ in range(args.warmup):
         step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
-    plan_ms = []
+    kernel_ms, plan_ms, pr_ms, scan_ms = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         t = job.timing()
         kernel_ms.append(t.pileup_ms)
         plan_ms.append(t.plan_ms)
+        pr_ms.append(t.per_read_ms)
+        scan_ms.append(t.per_read_scan_ms)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         # outside the data path: MAX of elapsed, SUM of bases
-        elapsed, total_B = partition.reduce_timing(dist, elapsed, B, device="cuda" if backend == "nccl" else "cpu")
+        elapsed, total_B = partition.reduce_timing(dist, elapsed, B, device=wire)
     else:
         total_B = B
 
-    # sanity outside the timed region: device depth sum == host-counted aligned bases
+    # sanity outside the timed region: device depth sum against the host-counted aligned bases
     sums = job.column_sums()
     if dist is not None:
         # after the merge: depth over the rows each rank OWNS, summed over ranks, is every
@@ -169,67 +321,102 @@ def main():
         dist.all_reduce(both)
         if int(both[0]) != int(both[1]):
             raise SystemExit(f"merged depth over owned rows {int(both[0])} != aligned bases of all ranks {int(both[1])}")
-    elif sums[0] != B and not os.environ.get("BENCH_TUNING_NO_CHECK"):  # tuning builds may be wrong on purpose
+    elif os.environ.get("BENCH_TUNING_NO_CHECK"):  # tuning builds may be wrong on purpose
+        pass
+    elif o.Stitch:
+        # positions both mates cover count once (pileup.go:409-430)
+        if not (B // 2 <= sums[0] <= B):
+            raise SystemExit(f"stitched device depth sum {sums[0]} outside [{B // 2}, {B}]")
+    elif sums[0] != B:
         raise SystemExit(f"device depth sum {sums[0]} != host aligned bases {B}")
     algo_bytes = job.algorithmic_bytes()
     n_rows = job.num_rows
     tm = job.timing()
+    n_feat = int(job.lib.bp_per_read_total(job.h)) if per_read else 0
+    if per_read and n_feat != sum(sums[1:9]):
+        raise SystemExit(f"{n_feat} list entries != {sum(sums[1:9])} counted bases")
 
     cpu = None
     if rank == 0 and pworld == 1 and not args.no_cpu_baseline:
         import oracle_lib as O
-        sample_bp = int(min(args.cpu_sample_mb * 1e6, L))
-        hi = int(np.searchsorted(rb.pos, sample_bp, "left"))
+        oopts = O.make_opts(clip=o.Clip, mapq=o.Mapq, min_base_qual=o.MinBaseQual, stitch=int(o.Stitch))
+        if cname == "c4":
+            sample_bed = {0: targets}
+            hi = rb.n
+            what = "all 500 targets"
+            n_cmp = 200 * len(targets)
+        else:
+            mb = args.cpu_sample_mb if args.cpu_sample_mb is not None else (20.0 if per_read else 100.0 if o.Stitch else 200.0)
+            sample_bp = int(min(mb * 1e6, L))
+            sample_bed = {0: [[0, sample_bp]]}
+            hi = int(np.searchsorted(rb.pos, sample_bp + (1200 if o.Stitch else 0), "left"))
+            what = f"first {sample_bp / 1e6:.0f} Mb"
+            n_cmp = sample_bp - 1200
         sample = rb.slice(0, hi)
-        oopts = O.make_opts()
         tc = time.perf_counter()
-        wr, wp, wv = O.pileup(oopts, [L], {0: [[0, sample_bp]]}, sample, parallelism=1)
+        if per_read:
+            wr, wp, wv, woff, wfeat = O.pileup_per_read(oopts, ref_lens, sample_bed, sample, parallelism=1)
+        else:
+            wr, wp, wv = O.pileup(oopts, ref_lens, sample_bed, sample, parallelism=1)
         cpu_s = time.perf_counter() - tc
-        cpu_B = int(wv[:, 0].sum())
+        cpu_B = kept_aligned_bases(sample, opts_kw, sample_bed[0])
         # and it is a parity check too: same rows from the device
-        dr, dp, dv = job.rows(0, sample_bp - 600)
-        if not (dv == wv[:sample_bp - 600]).all():
+        dr, dp, dv = job.rows(0, n_cmp)
+        if not (dv == wv[:n_cmp]).all():
             raise SystemExit("device rows differ from the CPU oracle on the baseline sample")
+        if per_read:
+            doff, dfeat = job.per_read(0, n_cmp)
+            if not ((doff == woff[:4 * n_cmp + 1]).all() and dfeat.tobytes() == wfeat[:int(woff[4 * n_cmp])].tobytes()):
+                raise SystemExit("device per-read lists differ from the CPU oracle on the baseline sample")
         cpu = {"value": round(cpu_B / cpu_s / 1e9, 4), "unit": "Gbase/s", "cores": 1, "kind": "port",
-               "sample": f"first {sample_bp / 1e6:.0f} Mb of the same workload ({hi} records, "
-                         f"{cpu_B} aligned bases) in {cpu_s:.1f} s, records in memory -> rows, "
+               "sample": f"{what} of the same workload ({hi} records, {cpu_B} aligned bases on the sample's BED) in "
+                         f"{cpu_s:.1f} s, records in memory -> rows{' + per-read lists' if per_read else ''}, same options, "
                          f"C restatement of the reference algorithm (oracle/pileup_oracle.c), 1 thread"}
         del wr, wp, wv, dr, dp, dv
-        # the same restatement on all host cores of the box's share: independent position
-        # ranges with a read halo, like the reference's jobs (pileup.go:862-932)
-        from concurrent.futures import ThreadPoolExecutor
-        T = min(16, os.cpu_count() or 1)
-        edges = [L * i // T for i in range(T + 1)]
+        if cname == "c2":
+            # the same restatement on all host cores of the box's share: independent position
+            # ranges with a read halo, like the reference's jobs (pileup.go:862-932)
+            from concurrent.futures import ThreadPoolExecutor
+            T = min(16, os.cpu_count() or 1)
+            edges = [L * i // T for i in range(T + 1)]
 
-        def one(i):
-            s, e = edges[i], edges[i + 1]
-            a = int(np.searchsorted(rb.pos, max(0, s - 1024), "left"))
-            b = int(np.searchsorted(rb.pos, e, "left"))
-            _, _, v = O.pileup(oopts, [L], {0: [[s, e]]}, rb.slice(a, b), parallelism=1)
-            return int(v[:, 0].sum())
-        tc = time.perf_counter()
-        with ThreadPoolExecutor(T) as ex:
-            mt_B = sum(ex.map(one, range(T)))
-        mt_s = time.perf_counter() - tc
-        if mt_B != B:
-            raise SystemExit(f"multi-threaded CPU run counted {mt_B} bases, expected {B}")
-        cpu["all_cores"] = {"value": round(mt_B / mt_s / 1e9, 4), "unit": "Gbase/s", "cores": T,
-                            "sample": f"the whole workload as {T} position ranges, one thread each, in {mt_s:.1f} s"}
-
-    # HBM traffic is not measurable inside this process (PMC counters need their own
-    # rocprofv3 passes): report the committed measurement of the same workload, if any
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj["workload"] == {"length": L, "coverage": args.coverage}:
-            traffic = tj["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+            def one(i):
+                s, e = edges[i], edges[i + 1]
+                a = int(np.searchsorted(rb.pos, max(0, s - 1024), "left"))
+                b = int(np.searchsorted(rb.pos, e, "left"))
+                _, _, v = O.pileup(oopts, [L], {0: [[s, e]]}, rb.slice(a, b), parallelism=1)
+                return int(v[:, 0].sum())
+            tc = time.perf_counter()
+            with ThreadPoolExecutor(T) as ex:
+                mt_B = sum(ex.map(one, range(T)))
+            mt_s = time.perf_counter() - tc
+            if mt_B != B:
+                raise SystemExit(f"multi-threaded CPU run counted {mt_B} bases, expected {B}")
+            cpu["all_cores"] = {"value": round(mt_B / mt_s / 1e9, 4), "unit": "Gbase/s", "cores": T,
+                                "sample": f"the whole workload as {T} position ranges, one thread each, in {mt_s:.1f} s"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         k_ms = float(np.mean(kernel_ms))
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        variant = ("stitched" if o.Stitch else "quality rule" if o.MinBaseQual else "every base passes") + (" + clip" if o.Clip else "")
+        kernels = [{"kernel": "bp::pileup_kernel", "variant": variant, "ms_avg": round(k_ms, 4),
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    "achieved_GBps": round(algo_bytes / (k_ms * 1e-3) / 1e9, 1),
+                    "frac": round(algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}]
+        dom, dom_ms, dom_bytes = "bp::pileup_kernel", k_ms, algo_bytes
+        if per_read:
+            g_ms = float(np.mean(pr_ms))
+            # the records once more + 44 B per row read + 6 B per entry written + 16 B of list offsets per row
+            g_bytes = algo_bytes + 6 * n_feat + 16 * n_rows
+            kernels.append({"kernel": "bp::per_read_kernel", "ms_avg": round(g_ms, 4),
+                            "algorithmic_bytes_per_launch": g_bytes, "list_entries": n_feat,
+                            "achieved_GBps": round(g_bytes / (g_ms * 1e-3) / 1e9, 1),
+                            "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "scan_ms_avg": round(float(np.mean(scan_ms)), 4)})
+            if g_ms > k_ms:
+                dom, dom_ms, dom_bytes = "bp::per_read_kernel", g_ms, g_bytes
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic(cname, dom)
         out = {
             "metric": "aligned bases piled up/sec",
             "value": round(total_B / (elapsed / args.steps) / 1e9, 3),
@@ -239,35 +426,35 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if cname == "c3" else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic {args.coverage:g}x chr1-sized contig ({L} bp) per GPU, 2x150 FR pairs, "
-                            "BED = whole contig, basestrand (per-strand) counts, DefaultOpts",
+                "workload": workload, "name": cname,
                 "records_per_gpu": rb.n, "aligned_bases_per_gpu": B, "bed_positions_per_gpu": n_rows,
-                "windows": int(tm.n_windows),
-                "partitioning": "one contig, one GPU" if world == 1 else
-                                f"one contig of {total_len} bp cut into {world} position ranges, reads partitioned by "
-                                f"start, {tail}-row boundary merge per step (all-gather of {tail * 44} B per rank)",
+                "windows": int(tm.n_windows), "gpus_arg": args.gpus, "world_size": world,
+                "partitioning": "one job, one GPU" if pworld == 1 else
+                                f"{total_len} bp cut into {pworld} position ranges, reads partitioned by start, "
+                                f"{tail}-row boundary merge per step (all-gather of {tail * 44} B per rank, stream-ordered)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "bp::pileup_kernel",
+                "bound": "hbm", "kernel": dom,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-                                  if traffic else None,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "kernel_ms_avg": round(k_ms, 4), "plan_ms_avg": round(float(np.mean(plan_ms)), 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "kernel_ms_avg": round(dom_ms, 4), "plan_ms_avg": round(float(np.mean(plan_ms)), 4),
+                "kernels": kernels,
                 "lds_atomics": {"achieved": round(B / (k_ms * 1e-3) / 1e9, 1), "peak": LDS_ATOMIC_PEAK_G,
                                 "unit": "G ds_add_u32 lanes/s", "frac": round(B / (k_ms * 1e-3) / 1e9 / LDS_ATOMIC_PEAK_G, 4)},
             },
             "cpu_baseline": cpu,
-            "setup": {"generate_s": round(gen_s, 1), "pack_and_h2d_s": round(submit_s, 2),
+            "setup": {"generate_s": round(gen_s, 1), "pack_and_h2d_s": round(submit_s, 2), "finish_s": round(finish_s, 3),
                       "h2d_inclusive_Gbase_per_s": round(B / (submit_s + elapsed / args.steps) / 1e9, 3),
                       "host_input_bytes": host_bytes},
         }
+        if emulate and world == 1:
+            out["config"]["emulated_rank"] = emulate
         print(json.dumps(out))
     job.close()
     sb.close()

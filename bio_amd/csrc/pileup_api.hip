@@ -128,6 +128,7 @@ struct bp_handle {
 
   // stitch: host mate table
   std::vector<MateRef> mate;                          // per record
+  bool mate_dirty = true;                             // changed since it was last copied to the device
   std::map<int32_t, std::vector<StoredRead>> stored;  // key: position the mate must start at
   int32_t stored_ref = -1;
   uint8_t qthr[96];
@@ -672,7 +673,10 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
       return fail(h, BP_ENOMEM, "bp_submit: more than 2^31-1 records in one job");
     spans.assign(ns, 0);
     simple.assign(ns, 0);
-    if (h->o.stitch) h->mate.resize((size_t)h->n_reads + ns, -1);
+    if (h->o.stitch) {
+      h->mate.resize((size_t)h->n_reads + ns, -1);
+      h->mate_dirty = true;
+    }
     if (int rc = scan_slice(h, b, i0, i1, spans, simple)) return rc;
     Staging* st = nullptr;
     if (int rc = acquire_stage(h, &st)) return rc;
@@ -823,7 +827,10 @@ int bp_compute(bp_handle* h) {
   if (h->o.stitch) {
     const size_t bytes = (size_t)h->n_reads * sizeof(MateRef);
     if (int rc = ensure(h, h->d_mate, std::max<size_t>(bytes, 256), 0)) return rc;
-    if (bytes) HIP_TRY(h, hipMemcpyAsync(h->d_mate.p, h->mate.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    // (only after a submit: pairing can reach back to records of earlier submits, so the whole
+    // table goes again then; a compute that follows a compute moves nothing)
+    if (bytes && h->mate_dirty) HIP_TRY(h, hipMemcpyAsync(h->d_mate.p, h->mate.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    h->mate_dirty = false;
   }
   if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
   if (int rc = ensure(h, h->d_cores, 256, 0)) return rc;
@@ -924,8 +931,11 @@ int bp_rows(bp_handle* h, int64_t first, int64_t n, int32_t* ref_id, int32_t* po
   if (first < 0 || n < 0 || first + n > h->n_rows) return fail(h, BP_EINVAL, "bp_rows: range [%lld,%lld) of %lld", (long long)first, (long long)(first + n), (long long)h->n_rows);
   if (n == 0) return BP_OK;
   HIP_TRY(h, hipSetDevice(h->device));
-  if (vals)
+  if (vals) {
+    // the job's stream does not synchronise with the null stream: wait for what the _async calls left on it
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(vals, (const uint32_t*)h->d_rows.p + first * BP_ROW_U32, (size_t)n * 44, hipMemcpyDeviceToHost));
+  }
   if (ref_id || pos) {
     size_t k = (size_t)(std::upper_bound(h->iv_row.begin(), h->iv_row.end(), first) - h->iv_row.begin()) - 1;
     int64_t done = 0;

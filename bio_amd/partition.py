@@ -133,22 +133,34 @@ def exchange_boundaries(dist, torch, job, own_rows, tail_rows, tail, rank, world
     rows stay in HBM; "cpu" only for the host-side stand-in job of the CPU tests)."""
     if world_size > 1 and own_rows < tail:
         raise ValueError(f"partition of {own_rows} positions is shorter than the {tail}-row boundary tail")
-    # The job works on its own HIP stream and torch (and RCCL under it) on theirs; every hand-over
-    # between the two is a full synchronisation: the zero fill must be done before the export
-    # writes into the same buffer, and the gathered rows must have arrived before the add reads
-    # them (a collective returns once it is queued, not once it is done).
     send = torch.zeros(tail * 11, dtype=torch.int32, device=stage)
     if stage == "cuda":
-        torch.cuda.synchronize()
+        # The job works on its own HIP stream and torch (and RCCL under it) on theirs.  The
+        # hand-overs are ordered on the device, by events, with no host wait: the export runs
+        # behind the zero fill, the collective behind the export, the add behind the collective
+        # (a collective called with async_op=False has torch's current stream wait for it).
+        js = torch.cuda.ExternalStream(job.stream)
+        cur = torch.cuda.current_stream()
+        js.wait_stream(cur)
+        if tail_rows:
+            job.rows_export_async(own_rows, tail_rows, send.data_ptr())
+        send.record_stream(js)  # the caching allocator must not hand the buffer out again before js is past it
+        cur.wait_stream(js)
+        wire = send if device == stage else send.to(device)
+        got = [torch.empty_like(wire) for _ in range(world_size)]
+        dist.all_gather(got, wire)
+        if rank > 0:
+            left = got[rank - 1] if device == stage else got[rank - 1].to(stage)
+            js.wait_stream(cur)
+            job.rows_accumulate_async(0, tail, left.data_ptr())
+            left.record_stream(js)
+        return
+    # host-side stand-in job (the CPU tests): plain calls, nothing is asynchronous
     if tail_rows:
-        job.rows_export(own_rows, tail_rows, send.data_ptr())  # returns when the copy is done
+        job.rows_export(own_rows, tail_rows, send.data_ptr())
     wire = send if device == stage else send.to(device)
     got = [torch.empty_like(wire) for _ in range(world_size)]
     dist.all_gather(got, wire)
-    if device == "cuda":
-        torch.cuda.synchronize()
     if rank > 0:
         left = got[rank - 1] if device == stage else got[rank - 1].to(stage)
-        if stage == "cuda":
-            torch.cuda.synchronize()
-        job.rows_accumulate(0, tail, left.data_ptr())  # returns when the add is done
+        job.rows_accumulate(0, tail, left.data_ptr())

@@ -323,6 +323,27 @@ def test_boundary_merge_on_device():
     got_pos = np.concatenate([jobs[g].rows(0, spans[g][0])[1] for g in range(G)])
     got_val = np.concatenate([jobs[g].rows(0, spans[g][0])[2] for g in range(G)])
     assert (got_pos == want[1]).all() and (got_val == want[2]).all()
+    # and bench.py's own exchange (partition.exchange_boundaries: hand-overs ordered by stream
+    # events, no host wait) with a stand-in for the collective that copies on torch's stream as
+    # RCCL would; the ranks take their turns in ascending order, so the left neighbour's tail
+    # is there when a rank gathers.  Fresh rows first.
+    class _Gather:
+        sent = {}
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def all_gather(self, got, wire):
+            _Gather.sent[self.rank] = wire.clone()
+            for r, t in enumerate(got):
+                if r in _Gather.sent:
+                    t.copy_(_Gather.sent[r], non_blocking=True)
+    for j in jobs:
+        j.compute()
+    for g in range(G):
+        P.exchange_boundaries(_Gather(g), torch, jobs[g], spans[g][0], spans[g][1], tail, g, G)
+    got_val2 = np.concatenate([jobs[g].rows(0, spans[g][0])[2] for g in range(G)])
+    assert (got_val2 == want[2]).all()
     with pytest.raises(snp.PileupError, match="out of range"):
         jobs[0].rows_export(spans[0][0], tail + 1, buf.data_ptr())
     with pytest.raises(snp.PileupError, match="null argument"):

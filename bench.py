@@ -450,6 +450,10 @@ def main():
             },
             "cpu_baseline": cpu,
             "setup": {"generate_s": round(gen_s, 1), "pack_and_h2d_s": round(submit_s, 2), "finish_s": round(finish_s, 3),
+                      # inside bp_submit: the serial pass in record order (order check, errors, mate pairing
+                      # in stitch mode) and the passes on all packing threads (spans, filters, hashes, packing)
+                      "submit_serial_scan_s": round(tm.submit_scan_ms / 1e3, 3),
+                      "submit_parallel_pack_s": round(tm.submit_pack_ms / 1e3, 3),
                       "h2d_inclusive_Gbase_per_s": round(B / (submit_s + elapsed / args.steps) / 1e9, 3),
                       "host_input_bytes": host_bytes},
         }

@@ -59,6 +59,8 @@ class bp_timing(C.Structure):
         ("n_items", C.c_int64),
         ("per_read_ms", C.c_float),
         ("per_read_scan_ms", C.c_float),
+        ("submit_scan_ms", C.c_float),
+        ("submit_pack_ms", C.c_float),
     ]
 
 

@@ -9,7 +9,7 @@
 // Host-side work that the reference also does per record before counting:
 //   * data errors (pileup.go:766-772, :355-359) are raised from bp_submit, in record order;
 //   * stitch mode: the mate table (firstread.go:176-204) is resolved here, because it is
-//     keyed by read name; the kernel receives one MateRef per record.
+//     keyed by read name; the kernel receives one MateEntry per record.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -18,7 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <map>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -85,11 +85,142 @@ struct Staging {
 constexpr size_t kStageReads = 1u << 20;       // records per staging slice
 constexpr size_t kStageBlob = 256u << 20;      // payload bytes per staging slice
 
-struct StoredRead {  // an entry of the firstread table (firstread.go:52-57)
-  std::string name;
+// The firstread table (firstreadSNPTable, firstread.go:79-204) on the host: reads waiting for
+// their mates.  The reference keeps a 2-D array of slices indexed by (pos mod nCirc, name hash);
+// here a ring of chains indexed by the position the read's mate has to start at (the read's
+// MatePos: tryRemove looks a read up by exactly that, firstread.go:136-145), entries and names in
+// pools, the 64-bit name hash computed beforehand on the packing threads and the name bytes
+// compared only when it matches.
+struct StoredRead {
+  uint64_t hash;
+  int32_t key_pos;   // its MatePos
   int32_t pos;
-  int64_t idx;
+  int64_t idx;       // record index in the job
+  uint32_t name_off, name_len;
+  MateEntry self;    // what its mate's entry of the mate table will say of it (x: flag bits only)
+  int32_t next;      // chain / free list
 };
+
+struct FirstReadTable {
+  std::vector<int32_t> head;   // [nCirc] chain heads, -1 = empty
+  std::vector<StoredRead> ents;
+  std::vector<char> names;
+  int32_t free_head = -1;
+  int64_t n_live = 0, live_name_bytes = 0;
+  int32_t ref = -1;
+  int64_t clean_upto = 0;      // chains of keys below it are empty
+  uint32_t mask = 0;
+
+  void init(int32_t max_read_span) {
+    uint32_t n = 1;
+    while (n <= (uint32_t)max_read_span) n <<= 1;  // live keys lie in [pos, pos + maxReadSpan]
+    head.assign(n, -1);
+    mask = n - 1;
+  }
+  void drop_chain(uint32_t slot) {
+    int32_t e = head[slot];
+    while (e >= 0) {
+      const int32_t nx = ents[(size_t)e].next;
+      live_name_bytes -= ents[(size_t)e].name_len;
+      ents[(size_t)e].next = free_head;
+      free_head = e;
+      n_live--;
+      e = nx;
+    }
+    head[slot] = -1;
+  }
+  void clear() {
+    if (n_live) for (uint32_t k = 0; k <= mask; k++) if (head[k] >= 0) drop_chain(k);
+    names.clear();
+  }
+  // Reads whose mate would have had to start before `pos` can never be matched again
+  // (records come in coordinate order): the reference evicts them as orphans (pileup.go:469-500).
+  void advance(int32_t r, int32_t pos) {
+    if (r != ref) {
+      clear();  // finishRef evicts every stored read (pileup.go:626)
+      ref = r;
+      clean_upto = pos;
+      return;
+    }
+    if (n_live == 0) {
+      clean_upto = pos;
+      if (!names.empty()) names.clear();
+      return;
+    }
+    int64_t from = clean_upto;
+    if ((int64_t)pos - from > (int64_t)mask + 1) from = (int64_t)pos - (int64_t)mask - 1;
+    for (int64_t p = from; p < pos; p++)
+      if (head[(uint32_t)p & mask] >= 0) drop_chain((uint32_t)p & mask);
+    clean_upto = pos;
+  }
+  void compact_names() {
+    std::vector<char> nn;
+    nn.reserve((size_t)live_name_bytes + 4096);
+    for (uint32_t k = 0; k <= mask; k++)
+      for (int32_t e = head[k]; e >= 0; e = ents[(size_t)e].next) {
+        StoredRead& s = ents[(size_t)e];
+        const uint32_t off = (uint32_t)nn.size();
+        nn.insert(nn.end(), names.begin() + s.name_off, names.begin() + s.name_off + s.name_len);
+        s.name_off = off;
+      }
+    names.swap(nn);
+  }
+  void add(const StoredRead& in, const uint8_t* name) {
+    if (names.size() + in.name_len > (64u << 20) && names.size() > 4 * (size_t)live_name_bytes + (1u << 20)) compact_names();
+    int32_t e = free_head;
+    if (e >= 0) free_head = ents[(size_t)e].next;
+    else { e = (int32_t)ents.size(); ents.emplace_back(); }
+    StoredRead& s = ents[(size_t)e];
+    s = in;
+    s.name_off = (uint32_t)names.size();
+    names.insert(names.end(), (const char*)name, (const char*)name + in.name_len);
+    const uint32_t slot = (uint32_t)in.key_pos & mask;
+    s.next = head[slot];
+    head[slot] = e;
+    n_live++;
+    live_name_bytes += in.name_len;
+  }
+  // tryRemove (firstread.go:135-152): the stored read that starts at `mate_pos`, expects its mate
+  // at `pos` and has this name; among several, the one stored first (see DESIGN: known differences).
+  bool try_remove(int32_t pos, int32_t mate_pos, uint64_t hash, const uint8_t* name, uint32_t name_len, StoredRead* out) {
+    const uint32_t slot = (uint32_t)pos & mask;
+    int32_t best = -1, best_prev = -1, prev = -1;
+    for (int32_t e = head[slot]; e >= 0; prev = e, e = ents[(size_t)e].next) {
+      const StoredRead& s = ents[(size_t)e];
+      if (s.hash == hash && s.key_pos == pos && s.pos == mate_pos && s.name_len == name_len &&
+          memcmp(names.data() + s.name_off, name, name_len) == 0 && (best < 0 || s.idx < ents[(size_t)best].idx)) {
+        best = e;
+        best_prev = prev;
+      }
+    }
+    if (best < 0) return false;
+    *out = ents[(size_t)best];
+    if (best_prev < 0) head[slot] = ents[(size_t)best].next;
+    else ents[(size_t)best_prev].next = ents[(size_t)best].next;
+    live_name_bytes -= ents[(size_t)best].name_len;
+    ents[(size_t)best].next = free_head;
+    free_head = best;
+    n_live--;
+    return true;
+  }
+};
+
+inline uint64_t name_hash(const uint8_t* p, size_t n) {
+  // 8 bytes at a time, multiply-mix (the hash only has to spread names; equality is checked on the bytes)
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ (n * 0xff51afd7ed558ccdull);
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 29;
+    p += 8;
+    n -= 8;
+  }
+  uint64_t w = 0;
+  memcpy(&w, p, n);
+  h = (h ^ w) * 0xff51afd7ed558ccdull;
+  return h ^ (h >> 32);
+}
 
 }  // namespace
 
@@ -127,10 +258,12 @@ struct bp_handle {
   int32_t cur_ref = 0;             // references < cur_ref are complete
 
   // stitch: host mate table
-  std::vector<MateRef> mate;                          // per record
+  std::vector<MateEntry> mate;                        // per record
   bool mate_dirty = true;                             // changed since it was last copied to the device
-  std::map<int32_t, std::vector<StoredRead>> stored;  // key: position the mate must start at
-  int32_t stored_ref = -1;
+  FirstReadTable stored;
+  std::vector<uint8_t> scan_cls;
+  std::vector<uint64_t> scan_hash;
+  double scan_s = 0, pack_s = 0;                      // host time in bp_submit so far: serial scan (order, errors, pairing) / parallel passes
   uint8_t qthr[96];
 
   // device
@@ -385,69 +518,127 @@ const char* ref_label(bp_handle* h, int32_t ref, char* tmp, size_t n) {
   return tmp;
 }
 
-// Per-record host pass over a slice: order check, data errors, span, stitch pairing.
-// Fills spans/simple for the packer.  Serial: it carries the mate table.
-int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1,
-               std::vector<int32_t>& spans, std::vector<uint8_t>& simple) {
+// What the parallel pass over a slice leaves per record for the serial one.
+enum : uint8_t {
+  SC_KEPT = 1,       // passes the read-level filters and the strand rule (pileup.go:691, :717-729), on a known reference
+  SC_TOO_LONG = 2,   // kept, and l_seq > maxReadLen or span > maxReadSpan (pileup.go:766-772)
+  SC_HITS = 4,       // kept and [pos, pos + span) meets the job's BED (pileup.go:773-777)
+  SC_BAD_OP = 8,     // its CIGAR holds an op outside MIDNSH
+  SC_PAIRABLE = 16,  // stitch: goes through the firstread table (firstread.go:180 does not send it on alone)
+  SC_MANY_OPS = 32   // more than 65535 CIGAR ops
+};
+
+// Host pass over a slice before it is packed.  First in parallel, record by record: span, the
+// read-level tests, the BED test, the name hash of reads that can pair.  Then serially, in record
+// order, what carries state: the order check, the per-reference record ranges, the coarse index,
+// the data errors (the first one in record order is the one reported, as the reference would
+// meet it) and the firstread table.  boff/qoff/blob_base: where the packer will put each record's
+// payload (a paired read's mate entry names it).
+int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, std::vector<int32_t>& spans,
+               std::vector<uint8_t>& simple, const std::vector<uint64_t>& boff, const std::vector<uint64_t>& qoff,
+               uint32_t blob_base, int nthreads) {
   const bp_opts& o = h->o;
-  for (int64_t i = i0; i < i1; i++) {
+  const size_t ns = (size_t)(i1 - i0);
+  std::vector<uint8_t>& cls = h->scan_cls;      // (scratch kept with the handle between slices)
+  std::vector<uint64_t>& hashes = h->scan_hash;
+  cls.assign(ns, 0);
+  if (o.stitch) hashes.resize(ns);
+  const int32_t nref = (int32_t)h->ref_len.size();
+  const auto t_par = std::chrono::steady_clock::now();
+  const size_t chunk = 8192;
+  parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
+    for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
+      const int64_t i = i0 + (int64_t)k;
+      const uint32_t n_cigar = b->n_cigar[i];
+      if (n_cigar > 0xffffu) {
+        cls[k] = SC_MANY_OPS;
+        continue;
+      }
+      bool simp = false, has_bad = false;
+      const int32_t span = cigar_span(b->cigar + b->cigar_off[i], n_cigar, &simp, &has_bad);
+      spans[k] = span;
+      simple[k] = simp ? 1 : 0;
+      const int32_t ref = b->ref_id[i], pos = b->pos[i];
+      const uint32_t flags = b->flags[i];
+      if (((uint32_t)o.flag_exclude & flags) != 0 || o.mapq > (int32_t)b->mapq[i] || n_cigar == 0) continue;
+      if (ref < 0 || ref >= nref) continue;  // unmapped: never in a shard
+      const int strand = strand_of(ref, b->mate_ref_id[i], flags);
+      if (o.strand_req != BP_STRAND_NONE) {
+        if (strand != o.strand_req) continue;
+      } else if (strand == 0 && !o.ignore_strand) {
+        continue;
+      }
+      uint8_t f = SC_KEPT;
+      if ((int64_t)b->l_seq[i] > (int64_t)o.max_read_len || span > o.max_read_span) {
+        cls[k] = f | SC_TOO_LONG;
+        continue;
+      }
+      const int32_t map_end = pos + span;
+      if (bed_intersects(h->bed[(size_t)ref], pos, map_end)) {
+        f |= SC_HITS;
+        if (has_bad) f |= SC_BAD_OP;
+        if (o.stitch) {
+          // firstreadSNPTable.addOrRemove (firstread.go:180): processed alone right away?
+          const int32_t mate_pos = b->mate_pos[i];
+          if (!(strand == 0 || mate_pos >= map_end || (int64_t)mate_pos + o.max_read_span <= (int64_t)pos)) {
+            f |= SC_PAIRABLE;
+            hashes[k] = name_hash(b->name + b->name_off[i], (size_t)(b->name_off[i + 1] - b->name_off[i]));
+          }
+        }
+      }
+      cls[k] = f;
+    }
+  });
+  const auto t_ser = std::chrono::steady_clock::now();
+  h->pack_s += std::chrono::duration<double>(t_ser - t_par).count();
+  struct Timer {
+    bp_handle* h;
+    std::chrono::steady_clock::time_point t0;
+    ~Timer() { h->scan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  } timer{h, t_ser};
+
+  for (size_t k = 0; k < ns; k++) {
+    const int64_t i = i0 + (int64_t)k;
+    const int64_t gidx = h->n_reads + (int64_t)k;
     const int32_t ref = b->ref_id[i], pos = b->pos[i];
     const uint64_t key = sort_key(ref, pos);
     if (key < h->last_key)
       return fail(h, BP_EUNSORTED, "bp_submit: record %lld (ref %d pos %d) is out of coordinate order",
-                  (long long)(h->n_reads + (i - i0)), ref, pos);
+                  (long long)gidx, ref, pos);
     h->last_key = key;
     {
       // records of reference r occupy [ref_first[r], ref_first[r+1]); unmapped (-1) sort last
-      const int32_t nref = (int32_t)h->ref_len.size();
       const int32_t rclamp = (ref < 0 || ref >= nref) ? nref : ref;
-      while (h->cur_ref < rclamp) h->ref_first[(size_t)++h->cur_ref] = h->n_reads + (i - i0);
+      while (h->cur_ref < rclamp) h->ref_first[(size_t)++h->cur_ref] = gidx;
     }
-    const uint32_t n_cigar = b->n_cigar[i];
-    if (n_cigar > 0xffffu)
-      return fail(h, BP_EINVAL, "bp_submit: record with %u CIGAR ops (limit 65535)", n_cigar);
-    const uint32_t* cg = b->cigar + b->cigar_off[i];
-    bool simp = false, has_bad = false;
-    const int32_t span = cigar_span(cg, n_cigar, &simp, &has_bad);
-    spans[(size_t)(i - i0)] = span;
-    simple[(size_t)(i - i0)] = simp ? 1 : 0;
-    const int64_t gidx = h->n_reads + (i - i0);
     if ((gidx & (kCoarse - 1)) == 0) h->coarse_pos.push_back(pos);
-    if (o.stitch) h->mate[(size_t)gidx] = -1;
-    // read-level filters (pileup.go:691, :717-729)
-    const uint32_t flags = b->flags[i];
-    if (((uint32_t)o.flag_exclude & flags) != 0 || o.mapq > (int32_t)b->mapq[i] || n_cigar == 0) continue;
-    if (ref < 0 || (size_t)ref >= h->ref_len.size()) continue;  // unmapped: never in a shard
-    const int strand = strand_of(ref, b->mate_ref_id[i], flags);
-    if (o.strand_req != BP_STRAND_NONE) {
-      if (strand != o.strand_req) continue;
-    } else if (strand == 0 && !o.ignore_strand) {
-      continue;
-    }
-    // ring-buffer sizing assumptions (pileup.go:766-772), checked before the BED test
+    const uint8_t f = cls[k];
+    if (!f) continue;
+    if (f & SC_MANY_OPS)
+      return fail(h, BP_EINVAL, "bp_submit: record with %u CIGAR ops (limit 65535)", b->n_cigar[i]);
+    const int32_t span = spans[k];
     char tmp[32];
-    if ((int64_t)b->l_seq[i] > (int64_t)o.max_read_len)
-      return fail(h, BP_EDATA,
-                  "pileupMutable.processShard: maxReadLen is %d, but read %s at %s:%d has length %u",
-                  o.max_read_len, read_name(b, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
-                  b->l_seq[i]);
-    if (span > o.max_read_span)
+    if (f & SC_TOO_LONG) {
+      // ring-buffer sizing assumptions (pileup.go:766-772), checked before the BED test
+      if ((int64_t)b->l_seq[i] > (int64_t)o.max_read_len)
+        return fail(h, BP_EDATA,
+                    "pileupMutable.processShard: maxReadLen is %d, but read %s at %s:%d has length %u",
+                    o.max_read_len, read_name(b, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
+                    b->l_seq[i]);
       return fail(h, BP_EDATA,
                   "pileupMutable.processShard: maxReadSpan is %d, but read %s at %s:%d has span %d",
                   o.max_read_span, read_name(b, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
                   span);
+    }
     if (span > h->max_span) h->max_span = span;
-    const int32_t map_end = pos + span;
-    const std::vector<int32_t>& e = h->bed[(size_t)ref];
-    const bool hits = bed_intersects(e, pos, map_end);
-    if (!hits) continue;
-    if (has_bad) {
+    if (f & SC_BAD_OP) {
       // alignRelevantBases (pileup.go:355-359) fails at the first op outside MIDNSH that its
       // walk reaches, i.e. one starting before the end of the last overlapping interval.
-      const int32_t last_end = bed_last_overlap_end(e, map_end);
+      const uint32_t* cg = b->cigar + b->cigar_off[i];
+      const int32_t last_end = bed_last_overlap_end(h->bed[(size_t)ref], pos + span);
       int32_t rp = pos;
-      for (uint32_t k = 0; k < n_cigar; k++) {
-        uint32_t op = cg[k] & 15u, len = cg[k] >> 4;
+      for (uint32_t c = 0; c < b->n_cigar[i]; c++) {
+        uint32_t op = cg[c] & 15u, len = cg[c] >> 4;
         if (rp >= last_end) break;
         if (op == 0 || op == 2 || op == 3) rp += (int32_t)len;
         else if (op > 5)
@@ -456,40 +647,42 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1,
                       ref_label(h, ref, tmp, sizeof tmp), pos);
       }
     }
-    if (!o.stitch) continue;
+    if (!(f & SC_PAIRABLE)) continue;
+#ifdef BP_EXP_NOPAIR
+    continue;
+#endif
     // firstreadSNPTable.addOrRemove (firstread.go:176-204)
-    if (h->stored_ref != ref) {
-      h->stored.clear();  // finishRef evicts every stored read as an orphan (pileup.go:626)
-      h->stored_ref = ref;
-    }
-    // entries whose mate position is behind us can never be matched again
-    while (!h->stored.empty() && h->stored.begin()->first < pos) h->stored.erase(h->stored.begin());
+    FirstReadTable& T = h->stored;
+    T.advance(ref, pos);
     const int32_t mate_pos = b->mate_pos[i];
-    if (strand == 0 || mate_pos >= map_end || (int64_t)mate_pos + o.max_read_span <= (int64_t)pos)
-      continue;  // processed alone now
+    const uint8_t* nm = b->name + b->name_off[i];
+    const uint32_t nlen = (uint32_t)(b->name_off[i + 1] - b->name_off[i]);
+    const int strand = strand_of(ref, b->mate_ref_id[i], b->flags[i]);
+    StoredRead me{};
+    me.hash = hashes[k];
+    me.key_pos = mate_pos;
+    me.pos = pos;
+    me.idx = gidx;
+    me.name_len = nlen;
+    me.self.x = (simple[k] ? MATE_SIMPLE : 0u) | MATE_HAS;
+    me.self.blob = blob_base + (uint32_t)(boff[k] / 8);
+    me.self.span_lseq = (uint32_t)span | ((uint32_t)b->l_seq[i] << 16);
+    me.self.ncig_qdelta = b->n_cigar[i] | ((uint32_t)((qoff[k] - boff[k]) / 8) << 16);
     if (pos >= mate_pos) {
-      // tryRemove: stored read at mate_pos with the same name and MatePos == pos
-      auto it = h->stored.find(pos);
-      bool found = false;
-      if (it != h->stored.end()) {
-        const std::string nm = read_name(b, i);
-        std::vector<StoredRead>& v = it->second;
-        for (size_t k = 0; k < v.size(); k++) {
-          if (v[k].pos == mate_pos && v[k].name == nm) {
-            const int64_t a = v[k].idx;
-            if (gidx >= (1ll << 30))
-              return fail(h, BP_EINVAL, "bp_submit: stitch mode supports at most 2^30 records per job");
-            h->mate[(size_t)gidx] = (MateRef)((a << 1) | 1);
-            h->mate[(size_t)a] = (MateRef)(gidx << 1);
-            v.erase(v.begin() + (long)k);
-            found = true;
-            break;
-          }
-        }
+      StoredRead a;
+      if (T.try_remove(pos, mate_pos, me.hash, nm, nlen, &a)) {
+        // the pair is counted on the strand of the read that found its mate (pileup.go:799-802)
+        const uint32_t rev = (!o.ignore_strand && strand == 2) ? MATE_PAIR_REV : 0u;
+        MateEntry eb = a.self, ea = me.self;
+        eb.x |= ((uint32_t)(a.pos - pos) & 0x1ffffu) | MATE_SECOND | rev;
+        ea.x |= ((uint32_t)(pos - a.pos) & 0x1ffffu) | rev;
+        h->mate[(size_t)gidx] = eb;
+        h->mate[(size_t)a.idx] = ea;
+        continue;
       }
-      if (found || pos != mate_pos) continue;
+      if (pos != mate_pos) continue;  // missing mate: processed alone
     }
-    h->stored[mate_pos].push_back(StoredRead{read_name(b, i), pos, gidx});
+    T.add(me, nm);
   }
   return 0;
 }
@@ -569,6 +762,7 @@ int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const 
   h->bed.resize((size_t)n_ref);
   h->ref_first.assign((size_t)n_ref + 1, 0);
   if (int rc = build_qthr(h)) { delete h; return rc; }
+  h->stored.init(opts->max_read_span);
   auto bail = [&](const char* what, hipError_t e) {
     int rc = fail(nullptr, BP_EDEVICE, "%s: %s", what, hipGetErrorString(e));
     bp_destroy(h);
@@ -674,15 +868,16 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
     spans.assign(ns, 0);
     simple.assign(ns, 0);
     if (h->o.stitch) {
-      h->mate.resize((size_t)h->n_reads + ns, -1);
+      h->mate.resize((size_t)h->n_reads + ns, MateEntry{0, 0, 0, 0});
       h->mate_dirty = true;
     }
-    if (int rc = scan_slice(h, b, i0, i1, spans, simple)) return rc;
+    if (int rc = scan_slice(h, b, i0, i1, spans, simple, boff, qoff, (uint32_t)h->blob_used, nthreads)) return rc;
     Staging* st = nullptr;
     if (int rc = acquire_stage(h, &st)) return rc;
     const uint32_t blob_base = (uint32_t)h->blob_used;
     std::atomic<int64_t> algo(0);
     const size_t chunk = 4096;
+    const auto t_pack = std::chrono::steady_clock::now();
     parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
       int64_t local = 0;
       for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
@@ -728,6 +923,7 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
       }
       algo.fetch_add(local);
     });
+    h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
     h->algo_in_bytes += algo.load();
     // device capacity, then async copies
     if (int rc = ensure(h, h->d_cores, ((size_t)h->n_reads + ns) * sizeof(ReadCore), (size_t)h->n_reads * sizeof(ReadCore))) return rc;
@@ -760,7 +956,7 @@ static int64_t item_capacity(const bp_handle* h) {
 static void fill_params(bp_handle* h, KernelParams& P) {
   P.cores = (const ReadCore*)h->d_cores.p;
   P.blob = (const uint8_t*)h->d_blob.p;
-  P.mate = h->o.stitch ? (const MateRef*)h->d_mate.p : nullptr;
+  P.mate = h->o.stitch ? (const MateEntry*)h->d_mate.p : nullptr;
   P.windows = (const Window*)h->d_windows.p;
   P.win_r0 = (const int32_t*)h->d_r0.p;
   P.win_r1 = (const int32_t*)h->d_r1.p;
@@ -825,7 +1021,7 @@ int bp_compute(bp_handle* h) {
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = freeze_bed(h)) return rc;
   if (h->o.stitch) {
-    const size_t bytes = (size_t)h->n_reads * sizeof(MateRef);
+    const size_t bytes = (size_t)h->n_reads * sizeof(MateEntry);
     if (int rc = ensure(h, h->d_mate, std::max<size_t>(bytes, 256), 0)) return rc;
     // (only after a submit: pairing can reach back to records of earlier submits, so the whole
     // table goes again then; a compute that follows a compute moves nothing)
@@ -1237,6 +1433,8 @@ int bp_render_fetch(bp_handle* h, char* out, size_t cap) {
 int bp_get_timing(const bp_handle* h, bp_timing* out) {
   if (!h || !out) return BP_EINVAL;
   *out = h->timing;
+  out->submit_scan_ms = (float)(h->scan_s * 1e3);
+  out->submit_pack_ms = (float)(h->pack_s * 1e3);
   return BP_OK;
 }
 

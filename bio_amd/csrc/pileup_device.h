@@ -69,9 +69,21 @@ struct Window {
 };
 static_assert(sizeof(Window) == 40, "Window must be 40 bytes");
 
-// mate table entry for stitch mode: -1 = processed alone, else (mate_index << 1) | second,
-// second = 1 for the read that found its mate in the table (readPair[0], firstread.go:187).
-typedef int32_t MateRef;
+// Mate table entry for stitch mode, one per record, all zero = processed alone.  It carries what
+// the kernel's phase 1 needs of the record's mate (firstread.go:176-204 decides the pairs, on the
+// host), so that no second record has to be fetched there:
+//   x     0..16 mate start - own start (17 bits two's complement; a pair lies within one span)
+//         17    this record found its mate in the table (readPair[0], firstread.go:187)
+//         18    strand slot the pair is counted on is "-" (the finder's strand, pileup.go:799-802)
+//         19    the mate's CIGAR is one M op          20    has a mate
+//   blob  the mate's payload offset (ReadCore::blob)
+//   span_lseq    mate span | mate l_seq << 16
+//   ncig_qdelta  mate n_cigar | mate qdelta << 16
+struct MateEntry {
+  uint32_t x, blob, span_lseq, ncig_qdelta;
+};
+static_assert(sizeof(MateEntry) == 16, "MateEntry must be 16 bytes");
+enum : uint32_t { MATE_SECOND = 1u << 17, MATE_PAIR_REV = 1u << 18, MATE_SIMPLE = 1u << 19, MATE_HAS = 1u << 20 };
 
 constexpr int kCoarse = 1024;  // stride of the coarse position index the plan kernel searches first
 
@@ -84,7 +96,7 @@ enum { ERR_NONE = 0, ERR_QUAL_RANGE = 1, ERR_ITEM_OVERFLOW = 2 };
 struct KernelParams {
   const ReadCore* cores;
   const uint8_t* blob;
-  const MateRef* mate;        // NULL unless stitch
+  const MateEntry* mate;      // NULL unless stitch
   const Window* windows;
   const int32_t* win_r0;      // per window: first record that may overlap it
   const int32_t* win_r1;      // per window: one past the last record starting before g1

@@ -170,7 +170,16 @@ constexpr int kUnitPos = 32;               // window positions per unit
 constexpr int kSub = kW / kUnitPos + 1;    // padded sub-row: 32 residues x kSub
 constexpr int kStride = kUnitPos * kSub;   // dwords per counter plane (multiple of 32)
 constexpr int kSegCap = BP_SEGCAP;   // M-segments per round
+// ... 448 in the variants that keep per-segment extras (stitch, clip): with them a workgroup's
+// LDS has to stay under half a CU's 160 KB
+#ifndef BP_SEGCAP_EXTRA
+#define BP_SEGCAP_EXTRA 448
+#endif
+constexpr int kSegCapExtra = BP_SEGCAP_EXTRA;
+template <bool EXTRA> constexpr int seg_cap() { return EXTRA ? kSegCapExtra : kSegCap; }
 constexpr int kUnitCap = BP_UNITCAP; // units (32 window positions of one segment) per round
+constexpr int kOvPerWave = (kUnitCap + kBlock - 1) / kBlock * 64;  // unit slots one wave issues per round
+static_assert(kUnitCap <= 4 * kBlock, "the overlap list encodes (iteration < 4, lane) in a byte");
 constexpr int kDepth = BP_DEPTH;     // units in flight per lane (software pipeline depth)
 constexpr int kDepthQ = BP_DEPTHQ;   // ... when the quals are loaded too
 constexpr int kWinPerBlock = BP_WINS; // consecutive windows per workgroup
@@ -187,18 +196,21 @@ constexpr int kWinPerBlock = BP_WINS; // consecutive windows per workgroup
 //  * flush: 32 consecutive positions of one plane sit at banks r + j: all distinct.
 // Per-segment fields only the stitched and clipped paths read back.
 struct SegExtra {
-  int32_t s_ref[kSegCap];       // segment start relative to the window start (may be < 0)
-  uint32_t s_lenq0[kSegCap];    // length | read offset << 16
-  uint32_t s_lseqnc[kSegCap];   // l_seq | n_cigar << 16
-  int32_t s_rec[kSegCap];       // record index
+  int32_t s_ref[kSegCapExtra];       // segment start relative to the window start (may be < 0)
+  uint32_t s_lenq0[kSegCapExtra];    // length | read offset << 16
+  uint32_t s_lseqnc[kSegCapExtra];   // l_seq | n_cigar << 16
+  int32_t s_rec[kSegCapExtra];       // record index
   // the M op of the record's mate that this segment can overlap (stitch; phase 1 cuts a
   // segment wherever the mate's next M op starts, so there is at most one): x = its start
   // relative to the window start, y = its length | this record is the one that found its
   // mate << 17 | has a mate << 18, z = mate payload offset, w = mate l_seq | n_cigar << 16;
   // s_mx = read index of its first base | mate qdelta << 16
-  uint4 s_mate[kSegCap];
-  uint32_t s_mx[kSegCap];
+  uint4 s_mate[kSegCapExtra];
+  uint32_t s_mx[kSegCapExtra];
   uint8_t qthr[96];             // KernelParams::qthr, "never" clamped to 96
+  // stitch: per wave, the units of this round with positions that the record's mate covers too
+  // and that this record has to decide (iteration << 6 | lane of the wave's first pass)
+  uint8_t ovl[kBlock / 64][kOvPerWave];
 };
 struct NoExtra {};
 
@@ -216,10 +228,11 @@ struct NoExtra {};
 template <bool EXTRA>
 struct __align__(16) BlockSharedT {
   uint32_t cnt[kPlanes * kStride];
-  uint4 seg[kSegCap];
+  uint4 seg[seg_cap<EXTRA>()];
   typename std::conditional<EXTRA, SegExtra, NoExtra>::type ex;
   uint16_t owner[kUnitCap];     // unit slot -> segment
   unsigned long long n_alloc[2];  // segments << 32 | units handed out this round (by round parity)
+  uint32_t more[2];               // a thread still has records of this window after this round (by round parity)
 };
 
 // Reference position -> read index of record `c` (mate lookup for the overlap rule).
@@ -369,7 +382,7 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
   const uint32_t base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
   const uint32_t excl = incl - mine;
   const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
-  const bool ok = idx + nseg <= (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
+  const bool ok = idx + nseg <= (uint32_t)seg_cap<EXTRA>() && us + U <= (uint32_t)kUnitCap;
   if (ok) {
     if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, qdelta, sslot, rec, miA, mxA);
     if (realB)
@@ -401,24 +414,41 @@ struct UnitLoad {
 // that every issue is the same number of VMEM instructions and the counted vmcnt waits stay
 // exact.  NEED_Q = false (min_base_qual 0, no stitching: every base passes the quality rule,
 // pileup.go:227) skips the qual loads altogether.
+// Slot order: neighbouring segments overlap on the genome, and lanes of one instruction
+// that add to the same counter serialise.  Chunks of BP_CHUNK consecutive slots (part of
+// one segment: distinct units, consecutive banks) are dealt out column-wise over a
+// (64 / BP_CHUNK) x R grid, so the chunks a wave holds are R chunks apart in slot order:
+// spread evenly over the round's units, i.e. over the window.  t = thread + iteration x block
+// -> unit slot (T: none).
+__device__ __forceinline__ uint32_t slot_of(uint32_t t, uint32_t T, uint32_t R) {
+  // (the LDS works on half-waves: lanes 0-31 take the even columns and lanes 32-63 the odd
+  // ones, so that each half spans the whole window)
+  constexpr uint32_t kCh = BP_CHUNK, kCols = 64 / kCh;
+#if BP_PERMUTE
+  const uint32_t a = t >> 6, ci = (t & 63u) / kCh;
+  const uint32_t b = ((ci % (kCols / 2)) << 1) | (ci / (kCols / 2));
+  t = a < R ? (((b * R + a) * kCh) | (t & (kCh - 1))) : T;  // rows past R hold no slots
+#endif
+  return t < T ? t : T;
+}
+
+// Stitching: the positions of unit jj of segment s that the record's mate covers too (every
+// segment overlaps at most one M op of the mate: phase 1 cuts them that way), and whether this
+// record is the one that decides them (it found its mate in the table, pileup.go:409-430).
+template <class SH>
+__device__ __forceinline__ uint32_t mate_overlap(const SH& S, uint32_t s, uint32_t jj, bool& second) {
+  const uint2 mi = *(const uint2*)&S.ex.s_mate[s];
+  second = (mi.y & 0x20000u) != 0;
+  if (!(mi.y & 0x40000u)) return 0u;
+  const int32_t lo = (int32_t)mi.x - (int32_t)(32u * jj), hi = lo + (int32_t)(mi.y & 0xffffu);
+  const int32_t l2 = lo > 0 ? lo : 0, h2 = hi < 32 ? hi : 32;
+  if (h2 <= l2) return 0u;
+  return h2 - l2 >= 32 ? 0xffffffffu : ((1u << (h2 - l2)) - 1u) << l2;
+}
+
 template <bool NEED_Q, bool STITCH, bool EXTRA>
 __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<EXTRA>& S, uint32_t t,
-                                           uint32_t T, uint32_t R, UnitLoad<NEED_Q, STITCH>& L) {
-  // Slot order: neighbouring segments overlap on the genome, and lanes of one instruction
-  // that add to the same counter serialise.  Chunks of BP_CHUNK consecutive slots (part of
-  // one segment: distinct units, consecutive banks) are dealt out column-wise over a
-  // (64 / BP_CHUNK) x R grid, so the chunks a wave holds are R chunks apart in slot order:
-  // spread evenly over the round's units, i.e. over the window.
-  {
-    // (the LDS works on half-waves: lanes 0-31 take the even columns and lanes 32-63 the odd
-    // ones, so that each half spans the whole window)
-    constexpr uint32_t kCh = BP_CHUNK, kCols = 64 / kCh;
-#if BP_PERMUTE
-    const uint32_t a = t >> 6, ci = (t & 63u) / kCh;
-    const uint32_t b = ((ci % (kCols / 2)) << 1) | (ci / (kCols / 2));
-    t = a < R ? (((b * R + a) * kCh) | (t & (kCh - 1))) : T;  // rows past R hold no slots
-#endif
-  }
+                                           uint32_t T, UnitLoad<NEED_Q, STITCH>& L) {
   bool in = t < T;
   uint32_t s = S.owner[in ? t : 0];
   if (s == 0xffffu) { in = false; s = 0; }
@@ -451,18 +481,13 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
     // that found its mate); that one fetches the mate's quals and bases over the unit now,
     // with the same wide loads as its own.
     const uint4 mi4 = S.ex.s_mate[s];
-    const bool mhas = in && (mi4.y & 0x40000u) != 0;
-    const bool second = (mi4.y & 0x20000u) != 0;
+    bool second;
+    uint32_t ov = in ? mate_overlap(S, s, jj, second) : 0u;
+    second = (mi4.y & 0x20000u) != 0;
     // mate read index of the unit's position 0
     const uint32_t mx = S.ex.s_mx[s];
     const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x + (int32_t)(mx & 0xffffu);
-    uint32_t ov = 0;
-    if (mhas) {
-      const int32_t lo = (int32_t)mi4.x - (int32_t)(32u * jj), hi = lo + (int32_t)(mi4.y & 0xffffu);
-      const int32_t l2 = lo > 0 ? lo : 0, h2 = hi < 32 ? hi : 32;
-      if (h2 > l2) ov = (h2 - l2 >= 32 ? 0xffffffffu : ((1u << (h2 - l2)) - 1u) << l2);
-      if (!second) { L.mask &= ~ov; ov = 0; }
-    }
+    if (!second) { L.mask &= ~ov; ov = 0; }
     ov &= L.mask;
     L.ov32 = ov;
     L.meta |= second ? 0x40000u : 0u;
@@ -497,8 +522,8 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
 // alone, and only the positions the record's mate also covers are patched afterwards
 // (addReadPair, pileup.go:406-446): the record that was stored first drops them, the one that
 // found its mate decides them from both reads (equal bases: qualSumTable threshold, else X).
-template <bool STITCH, bool CLIP, bool MINQ0>
-__device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
+template <bool STITCH, bool CLIP, bool MINQ0, class SH>
+__device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B,
                                                    const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t cpo) {
   static_assert(!(STITCH && MINQ0), "the stitched path always reads the quals");
   constexpr uint32_t M1 = 0x11111111u;
@@ -654,8 +679,8 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, BlockS
   }
 }
 
-template <bool STITCH, bool CLIP, bool MINQ0>
-__device__ __forceinline__ void unit(const KernelParams& P, BlockSharedT<STITCH || CLIP>& B,
+template <bool STITCH, bool CLIP, bool MINQ0, class SH>
+__device__ __forceinline__ void unit(const KernelParams& P, SH& B,
                                      const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t cpo) {
   process_unit_plain<STITCH, CLIP, MINQ0 && !STITCH>(P, B, L, cpo);
 }
@@ -768,7 +793,10 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   }
 
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
-  if (tid == 0) S.n_alloc[0] = S.n_alloc[1] = 0;
+  if (tid == 0) {
+    S.n_alloc[0] = S.n_alloc[1] = 0;
+    S.more[0] = S.more[1] = 0;
+  }
   if constexpr (STITCH) {
     if (tid < 96) S.ex.qthr[tid] = P.qthr[tid] < 96 ? P.qthr[tid] : (uint8_t)96;
   }
@@ -795,10 +823,13 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     }
   }
   uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0;
+  // stitch: the record's entry of the mate table travels with its core
+  [[maybe_unused]] uint4 pme = pc0;
   if (n_r0 + tid < n_r1) {
     const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
     pc0 = cp[0];
     pc1 = cp[1];
+    if constexpr (STITCH) pme = ((const uint4*)P.mate)[n_r0 + tid];
   }
 
   for (uint32_t item = w_first; item < w_last; item += DEEP ? gridDim.x : 1u) {
@@ -818,15 +849,150 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 
     // per-thread record cursor
     int32_t rec = r0 + tid;
-    bool have = false, keep = false, prefetched = true, next_issued = false;
+    bool have = false, keep = false;
     uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, qdelta = 0, sslot = 0, aux = 0, span = 0;
     uint32_t cg0 = 0, cg1 = 0, cg2 = 0;
     uint4 minfo = make_uint4(0, 0, 0, 0);
     uint32_t mqd = 0;  // mate qdelta << 16
     int32_t rr = 0, qq = 0;
     int32_t rem_s = 0, rem_l = 0, rem_q = 0;  // stitch: rest of the M op being cut into pieces
-    uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
+    auto flush = [&]() {
 
+      // ---- flush: one lane per position; Depth = sum of the 12 planes (pileup.go:518-570);
+      // the planes are zeroed as they are read, ready for the next window
+      // The upper half of the waves takes three quarters of the positions: the lower half
+      // holds the records of the next window and moves on to its phase 1 meanwhile.
+      constexpr uint32_t kHalf = kBlock / 2, kCut = (uint32_t)kW / 8 * BP_FLUSH_UPPER;
+      const bool upper = (uint32_t)tid >= kHalf;
+      const uint32_t p_lo = upper ? (uint32_t)tid - kHalf : kCut + (uint32_t)tid;
+      const uint32_t p_hi = upper ? kCut : (uint32_t)kW;
+      const uint32_t p_end = ncopy > 1 ? nsub * 32u : (uint32_t)kW;  // columns past it hold the copies
+      for (uint32_t p = p_lo; p < p_hi; p += kHalf) {
+        if (p >= p_end) break;
+        uint32_t v[kPlanes];
+        uint32_t d = 0;
+        uint32_t* const cp = S.cnt + (p & 31u) * kSub + (p >> 5);
+  #pragma unroll
+        for (int c = 0; c < kPlanes; c++) {
+          v[c] = cp[c * kStride];
+          d += v[c];
+        }
+        if (d != 0) {
+  #pragma unroll
+          for (int c = 0; c < kPlanes; c++) cp[c * kStride] = 0;
+        }
+        for (uint32_t cc = 1; cc < ncopy; cc++) {
+          uint32_t* const cq = cp + cc * nsub;
+          uint32_t dd = 0;
+  #pragma unroll
+          for (int c = 0; c < kPlanes; c++) {
+            const uint32_t x = cq[c * kStride];
+            v[c] += x;
+            dd += x;
+          }
+          if (dd != 0) {
+  #pragma unroll
+            for (int c = 0; c < kPlanes; c++) cq[c * kStride] = 0;
+          }
+          d += dd;
+        }
+        if (p >= wlen) continue;
+        int64_t R;
+        if (win.full) {
+          R = win.row_base + p;
+        } else {
+          const int32_t gp = g0 + (int32_t)p;
+          uint32_t a = win.iv_lo, b = win.iv_hi;  // last interval with start <= gp
+          while (b - a > 1) {
+            const uint32_t m = (a + b) >> 1;
+            if (P.iv_start[m] <= gp) a = m; else b = m;
+          }
+          const int32_t is = P.iv_start[a];
+          if (gp < is || gp >= P.iv_end[a]) continue;  // not a BED position
+          R = P.iv_row[a] + (gp - is);
+        }
+        uint32_t* out = P.rows + R * 11;
+        if constexpr (DEEP) {
+          if (d != 0) {
+            atomicAdd(out, d);
+  #pragma unroll
+            for (int c = 0; c < 10; c++)
+              if (v[c]) atomicAdd(out + 1 + c, v[c]);
+          }
+        } else {
+          u32x4a o0 = {d, v[0], v[1], v[2]};
+          u32x4a o1 = {v[3], v[4], v[5], v[6]};
+          u32x3a o2 = {v[7], v[8], v[9]};
+          *(u32x4a*)(out) = o0;
+          *(u32x4a*)(out + 4) = o1;
+          *(u32x3a*)(out + 8) = o2;
+        }
+      }
+    };
+    // A record's core (and, stitching, its entry of the mate table) -> the per-thread cursor.
+    auto decode = [&](const uint4 c0, const uint4 c1, [[maybe_unused]] uint4 me) {
+      const int32_t pos = (int32_t)c0.x;
+      const uint32_t flags = c0.y & 0xffffu, mapq = (c0.y >> 16) & 0xffu;
+      aux = c0.y >> 24;
+      n_cigar = c0.z & 0xffffu;
+      span = c0.z >> 16;
+      const uint32_t l_seq = c0.w & 0xffffu;
+      blob = c1.x;
+      cg0 = c1.y; cg1 = c1.z; cg2 = c1.w;
+      lseqnc = l_seq | (n_cigar << 16);
+      qdelta = c0.w >> 16;
+      const int strand = strand_of((aux & AUX_MATE_SAME) != 0, flags);
+      // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
+      keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
+      // strand filters (pileup.go:717-729)
+      if (P.strand_req != 0) keep = keep && strand == P.strand_req;
+      else keep = keep && (strand != 0 || P.ignore_strand);
+      keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
+      sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
+      minfo = make_uint4(0, 0, 0, 0);
+      mqd = 0;
+      if constexpr (STITCH) {
+        // The record's entry of the mate table (MateEntry, pileup_device.h) says everything
+        // phase 1 needs to know of the mate, so the mate's core is never fetched: one load
+        // beside the record's own core instead of two dependent ones behind it.
+#ifdef BP_EXP_NOMATE
+        me.x = 0;
+#endif
+        if (keep && (me.x & MATE_HAS)) {
+          const int32_t delta = ((int32_t)(me.x << 15)) >> 15;  // mate start - own start, 17 bits signed
+          const uint32_t second = (me.x & MATE_SECOND) ? 1u : 0u;
+          // the pair is counted on the strand of the read that found its mate
+          // (pileup.go:799-802); for the stored read that is the mate's strand
+          if (!second && !P.ignore_strand) sslot = (me.x & MATE_PAIR_REV) ? 1u : 0u;
+          minfo.x = (uint32_t)(pos + delta - g0);
+          minfo.y = (me.z & 0xffffu) | ((me.x & MATE_SIMPLE) ? 0x10000u : 0u) | (second << 17) | 0x40000u;  // bit 16: one M op
+          minfo.z = me.y;
+          minfo.w = (me.z >> 16) | ((me.w & 0xffffu) << 16);
+          mqd = me.w & 0xffff0000u;
+        }
+      }
+      c_cur = 0;
+      rr = pos - g0;
+      qq = 0;
+      rem_l = 0;
+      have = true;
+    };
+    // round 0 works on the records fetched a window ahead; the registers they came in are free
+    // from here on (the next window's are fetched in the last round, behind its phase 1)
+    // Two loop shapes.  LATE (the stitched kernels, which live at the register limit): the
+    // records fetched a window ahead are decoded before the loop and the next window's are
+    // fetched in the window's LAST round, so their registers are never live during a phase 1;
+    // the round's first barrier settles "last" through a flag in LDS.  Otherwise: fetched in
+    // round 0 and the end-of-round barrier is the block-wide vote (measured faster there:
+    // 4.35 against 4.55 ms on chr1 30x).
+    constexpr bool LATE = STITCH;
+    [[maybe_unused]] bool first_round = true;
+    if constexpr (LATE) {
+      if (rec < r1) decode(pc0, pc1, pme);
+    }
+    uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
+    [[maybe_unused]] uint4 nme = nc0;
+    [[maybe_unused]] bool next_issued = false;
     for (;;) {
       // (no barrier here: the slot counter of this round was reset behind the previous
       // round's first barrier, and phase 1 touches nothing the flush still reads)
@@ -834,57 +1000,16 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
       const bool has_rec = rec < r1;
       if (has_rec && !have) {
-        uint4 c0 = pc0, c1 = pc1;
-        if (!prefetched) {
+        uint4 c0 = pc0, c1 = pc1, me = pme;
+        if (LATE || !first_round) {
           const uint4* cp = (const uint4*)(P.cores + rec);
           c0 = cp[0];
           c1 = cp[1];
+          if constexpr (STITCH) me = ((const uint4*)P.mate)[rec];
         }
-        const int32_t pos = (int32_t)c0.x;
-        const uint32_t flags = c0.y & 0xffffu, mapq = (c0.y >> 16) & 0xffu;
-        aux = c0.y >> 24;
-        n_cigar = c0.z & 0xffffu;
-        span = c0.z >> 16;
-        const uint32_t l_seq = c0.w & 0xffffu;
-        blob = c1.x;
-        cg0 = c1.y; cg1 = c1.z; cg2 = c1.w;
-        lseqnc = l_seq | (n_cigar << 16);
-        qdelta = c0.w >> 16;
-        const int strand = strand_of((aux & AUX_MATE_SAME) != 0, flags);
-        // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
-        keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
-        // strand filters (pileup.go:717-729)
-        if (P.strand_req != 0) keep = keep && strand == P.strand_req;
-        else keep = keep && (strand != 0 || P.ignore_strand);
-        keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
-        sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
-        minfo = make_uint4(0, 0, 0, 0);
-        mqd = 0;
-        if constexpr (STITCH) {
-          if (keep) {
-            const int32_t m = P.mate[rec];
-            if (m >= 0) {
-              const uint4* mp = (const uint4*)(P.cores + (m >> 1));
-              const uint4 m0 = mp[0], m1 = mp[1];
-              const uint32_t maux = m0.y >> 24;
-              // the pair is counted on the strand of the read that found its mate
-              // (pileup.go:799-802); for the stored read that is the mate's strand
-              if (!(m & 1) && !P.ignore_strand)
-                sslot = (uint32_t)(strand_of((maux & AUX_MATE_SAME) != 0, m0.y & 0xffffu) - 1) & 1u;
-              minfo.x = (uint32_t)((int32_t)m0.x - g0);
-              minfo.y = (m0.z >> 16) | ((maux & AUX_SIMPLE) ? 0x10000u : 0u) | ((uint32_t)(m & 1) << 17) | 0x40000u;  // bit 16: one M op
-              minfo.z = m1.x;
-              minfo.w = (m0.w & 0xffffu) | ((m0.z & 0xffffu) << 16);
-              mqd = m0.w & 0xffff0000u;
-            }
-          }
-        }
-        c_cur = 0;
-        rr = pos - g0;
-        qq = 0;
-        rem_l = 0;
-        have = true;
+        decode(c0, c1, me);
       }
+      first_round = false;
       // CIGAR walk (pileup.go:275-363): every M op is one segment; the wave admits up to two
       // segments per lane per step, all lanes together
       bool more = has_rec && keep, failed = false;
@@ -957,15 +1082,24 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       if (has_rec && !failed) {
         rec += kBlock;
         have = false;
-        prefetched = false;
       }
+      // the barrier between the phases also settles whether this is the window's last round:
+      // a thread with records left says so in the round's flag (everybody stores the same 1)
       const int pending = rec < r1;
+      // LATE: a thread with records left says so in the round's flag (everybody stores the same 1)
+      if constexpr (LATE) {
+        if (pending) S.more[par] = 1u;
+      }
       BP_STAMP(2);
       __syncthreads();
+      bool last = false;
+      if constexpr (LATE) last = S.more[par] == 0u;
       BP_STAMP(3);
 
-      // ---- prefetch for the next window(s)
-      if (!next_issued) {
+      // ---- prefetch for the next window: everything it needs from global memory before its
+      // unit loads (window descriptor, record range two ahead, this thread's first record core)
+      // is fetched while this window is in phase 2 and flushed
+      if (LATE ? last : !next_issued) {
         next_issued = true;
         if constexpr (DEEP) {
           if (item + gridDim.x < w_last) {
@@ -977,6 +1111,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
               const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
               nc0 = cp[0];
               nc1 = cp[1];
+              if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
             }
           }
         } else if (item + 1 < w_last) {
@@ -987,6 +1122,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
             const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
             nc0 = cp[0];
             nc1 = cp[1];
+            if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
           }
           if (item + 2 < w_last) {
             nn_r0 = P.win_r0[item + 2];
@@ -997,7 +1133,10 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 
       // ---- phase 2: thread = unit (32 window positions of one segment); kDepth units in
       // flight per lane
-      if (tid == 0) S.n_alloc[par ^ 1u] = 0;  // next round's counter; next touched after the barrier below
+      if (tid == 0) {  // next round's counter and flag; next touched after the barrier below
+        S.n_alloc[par ^ 1u] = 0;
+        S.more[par ^ 1u] = 0;
+      }
       const uint32_t n_alloc_u = (uint32_t)S.n_alloc[par];
       const uint32_t T = n_alloc_u < (uint32_t)kUnitCap ? n_alloc_u : (uint32_t)kUnitCap;
 #ifdef BP_STAMPS_P2
@@ -1012,7 +1151,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t0 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          issue_unit<NEED_Q, STITCH>(P, S, tb + (tid & 63), T, (T + 63) / 64, L1);
+          issue_unit<NEED_Q, STITCH>(P, S, slot_of(tb + (tid & 63), T, (T + 63) / 64), T, L1);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1039,110 +1178,87 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // flight; at 30x a window is 2-3 units per thread and the loop body rarely runs.
         // (with -clip one unit in flight: 6.40 -> 5.97 ms on chr1 30x; the clip masks' registers
         // are what a second unit's loads would have to live next to)
-        constexpr int kD = STITCH ? BP_DEPTHS : (NEED_Q ? (CLIP ? 1 : kDepthQ) : kDepth);
+        // Stitched runs make two passes.  The first takes every unit through the plain path with
+        // the quality rule, leaving out the positions the record's mate covers too (Depth++ once
+        // per pair position, pileup.go:409-430); a unit whose record has to decide such positions
+        // (it found its mate in the table) is noted in the wave's list.  The second pass takes
+        // only the listed units - few at whole-genome insert sizes - loads the mate's bases and
+        // quals next to the record's own and counts just those positions (process_unit_plain's
+        // stitched branch).  So the bulk of the units runs at the plain path's depth and register
+        // budget, and the mate's loads are issued only where they are used.
+        constexpr int kD = NEED_Q ? (CLIP ? 1 : kDepthQ) : kDepth;
         const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
         const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
-        UnitLoad<NEED_Q, STITCH> L[kD];
+        UnitLoad<NEED_Q, false> L[kD];
         uint32_t t = (uint32_t)tid;
+        uint32_t n_ov = 0;  // wave-uniform
+        [[maybe_unused]] const uint32_t lane = (uint32_t)tid & 63u, wv = (uint32_t)tid >> 6;
+        auto issue1 = [&](UnitLoad<NEED_Q, false>& U, uint32_t tt) {
+          issue_unit<NEED_Q, false>(P, S, slot_of(tt, T, R), T, U);
+          if constexpr (STITCH) {
+            bool second = false;
+            const bool in = (U.meta & 0x10000u) != 0;
+            const uint32_t ov = in ? mate_overlap(S, U.seg, U.meta & 0x3fu, second) & U.mask : 0u;
+            U.mask &= ~ov;
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(second && ov != 0);
+            if (second && ov != 0) {
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+              S.ex.ovl[wv][n_ov + rank] = (uint8_t)((((tt - (uint32_t)tid) / kBlock) << 6) | lane);
+            }
+            n_ov += (uint32_t)__builtin_popcountll(b);
+          }
+        };
 #pragma unroll
         for (int d = 0; d < kD; d++) {
-          issue_unit<NEED_Q, STITCH>(P, S, t, T, R, L[d]);
+          issue1(L[d], t);
           t += kBlock;
         }
         uint32_t it = 0;
         for (; it + kD < n_it; it += kD) {
 #pragma unroll
           for (int d = 0; d < kD; d++) {
-            unit<STITCH, CLIP, MINQ0>(P, S, L[d], cpo);
-            issue_unit<NEED_Q, STITCH>(P, S, t, T, R, L[d]);
+            unit<false, CLIP, MINQ0>(P, S, L[d], cpo);
+            issue1(L[d], t);
             t += kBlock;
           }
         }
         const uint32_t rem = n_it - it;
 #pragma unroll
         for (int d = 0; d < kD; d++)
-          if ((uint32_t)d < rem) unit<STITCH, CLIP, MINQ0>(P, S, L[d], cpo);
+          if ((uint32_t)d < rem) unit<false, CLIP, MINQ0>(P, S, L[d], cpo);
+#ifdef BP_EXP_NO2B_CT
+        if constexpr (false) {
+#else
+        if constexpr (STITCH) {
+#endif
+          __builtin_amdgcn_wave_barrier();  // the list is the wave's own: written above, read below
+#ifdef BP_EXP_NO2B
+          n_ov = 0;
+#endif
+          for (uint32_t b0 = 0; b0 < n_ov; b0 += 64) {
+            const bool in = b0 + lane < n_ov;
+            const uint32_t e = in ? S.ex.ovl[wv][b0 + lane] : 0u;
+            const uint32_t tt = ((uint32_t)tid & ~63u) + (e & 63u) + (e >> 6) * kBlock;
+            UnitLoad<true, true> M;
+            issue_unit<true, true>(P, S, in ? slot_of(tt, T, R) : T, T, M);
+            M.mask = M.ov32;  // everything else was counted in the first pass
+            unit<true, CLIP, false>(P, S, M, cpo);
+          }
+        }
       }
 #endif
       BP_STAMP(4);
       par ^= 1u;
-      if (!__syncthreads_or(pending)) break;
+      if constexpr (LATE) __syncthreads();
+      else last = !__syncthreads_or(pending);
+      if (last) break;
     }
     BP_STAMP(5);
-
-    // ---- flush: one lane per position; Depth = sum of the 12 planes (pileup.go:518-570);
-    // the planes are zeroed as they are read, ready for the next window
-    // The upper half of the waves takes three quarters of the positions: the lower half
-    // holds the records of the next window and moves on to its phase 1 meanwhile.
-    constexpr uint32_t kHalf = kBlock / 2, kCut = (uint32_t)kW / 8 * BP_FLUSH_UPPER;
-    const bool upper = (uint32_t)tid >= kHalf;
-    const uint32_t p_lo = upper ? (uint32_t)tid - kHalf : kCut + (uint32_t)tid;
-    const uint32_t p_hi = upper ? kCut : (uint32_t)kW;
-    const uint32_t p_end = ncopy > 1 ? nsub * 32u : (uint32_t)kW;  // columns past it hold the copies
-    for (uint32_t p = p_lo; p < p_hi; p += kHalf) {
-      if (p >= p_end) break;
-      uint32_t v[kPlanes];
-      uint32_t d = 0;
-      uint32_t* const cp = S.cnt + (p & 31u) * kSub + (p >> 5);
-#pragma unroll
-      for (int c = 0; c < kPlanes; c++) {
-        v[c] = cp[c * kStride];
-        d += v[c];
-      }
-      if (d != 0) {
-#pragma unroll
-        for (int c = 0; c < kPlanes; c++) cp[c * kStride] = 0;
-      }
-      for (uint32_t cc = 1; cc < ncopy; cc++) {
-        uint32_t* const cq = cp + cc * nsub;
-        uint32_t dd = 0;
-#pragma unroll
-        for (int c = 0; c < kPlanes; c++) {
-          const uint32_t x = cq[c * kStride];
-          v[c] += x;
-          dd += x;
-        }
-        if (dd != 0) {
-#pragma unroll
-          for (int c = 0; c < kPlanes; c++) cq[c * kStride] = 0;
-        }
-        d += dd;
-      }
-      if (p >= wlen) continue;
-      int64_t R;
-      if (win.full) {
-        R = win.row_base + p;
-      } else {
-        const int32_t gp = g0 + (int32_t)p;
-        uint32_t a = win.iv_lo, b = win.iv_hi;  // last interval with start <= gp
-        while (b - a > 1) {
-          const uint32_t m = (a + b) >> 1;
-          if (P.iv_start[m] <= gp) a = m; else b = m;
-        }
-        const int32_t is = P.iv_start[a];
-        if (gp < is || gp >= P.iv_end[a]) continue;  // not a BED position
-        R = P.iv_row[a] + (gp - is);
-      }
-      uint32_t* out = P.rows + R * 11;
-      if constexpr (DEEP) {
-        if (d != 0) {
-          atomicAdd(out, d);
-#pragma unroll
-          for (int c = 0; c < 10; c++)
-            if (v[c]) atomicAdd(out + 1 + c, v[c]);
-        }
-      } else {
-        u32x4a o0 = {d, v[0], v[1], v[2]};
-        u32x4a o1 = {v[3], v[4], v[5], v[6]};
-        u32x3a o2 = {v[7], v[8], v[9]};
-        *(u32x4a*)(out) = o0;
-        *(u32x4a*)(out + 4) = o1;
-        *(u32x3a*)(out + 8) = o2;
-      }
-    }
+    flush();
     BP_STAMP(6);
     pc0 = nc0;
     pc1 = nc1;
+    if constexpr (STITCH) pme = nme;
   }
 }
 

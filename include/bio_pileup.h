@@ -103,6 +103,11 @@ typedef struct bp_timing {
   int64_t n_items;   /* work items launched (windows x slices) */
   float per_read_ms; /* the gather kernel of the last bp_per_read_build (0 before one) */
   float per_read_scan_ms; /* ... and the scan of the counts before it (kernels + one host round trip) */
+  /* host time inside all bp_submit calls of the job so far: the serial pass in record order (order
+   * check, data errors, the firstread table of stitch mode) and the passes that run on all packing
+   * threads (spans, filters, name hashes, packing into the pinned staging buffers) */
+  float submit_scan_ms;
+  float submit_pack_ms;
 } bp_timing;
 
 /* Library/runtime probe.  Fails (BP_EDEVICE) when no HIP device is usable: there is no

@@ -170,16 +170,14 @@ constexpr int kUnitPos = 32;               // window positions per unit
 constexpr int kSub = kW / kUnitPos + 1;    // padded sub-row: 32 residues x kSub
 constexpr int kStride = kUnitPos * kSub;   // dwords per counter plane (multiple of 32)
 constexpr int kSegCap = BP_SEGCAP;   // M-segments per round
-// ... 448 in the variants that keep per-segment extras (stitch, clip): with them a workgroup's
+// ... 400 in the variants that keep per-segment extras (stitch, clip): with them a workgroup's
 // LDS has to stay under half a CU's 160 KB
 #ifndef BP_SEGCAP_EXTRA
-#define BP_SEGCAP_EXTRA 448
+#define BP_SEGCAP_EXTRA 400
 #endif
 constexpr int kSegCapExtra = BP_SEGCAP_EXTRA;
 template <bool EXTRA> constexpr int seg_cap() { return EXTRA ? kSegCapExtra : kSegCap; }
 constexpr int kUnitCap = BP_UNITCAP; // units (32 window positions of one segment) per round
-constexpr int kOvPerWave = (kUnitCap + kBlock - 1) / kBlock * 64;  // unit slots one wave issues per round
-static_assert(kUnitCap <= 4 * kBlock, "the overlap list encodes (iteration < 4, lane) in a byte");
 constexpr int kDepth = BP_DEPTH;     // units in flight per lane (software pipeline depth)
 constexpr int kDepthQ = BP_DEPTHQ;   // ... when the quals are loaded too
 constexpr int kWinPerBlock = BP_WINS; // consecutive windows per workgroup
@@ -208,9 +206,9 @@ struct SegExtra {
   uint4 s_mate[kSegCapExtra];
   uint32_t s_mx[kSegCapExtra];
   uint8_t qthr[96];             // KernelParams::qthr, "never" clamped to 96
-  // stitch: per wave, the units of this round with positions that the record's mate covers too
-  // and that this record has to decide (iteration << 6 | lane of the wave's first pass)
-  uint8_t ovl[kBlock / 64][kOvPerWave];
+  // stitch: the unit slots of this round with positions that the record's mate covers too and
+  // that this record has to decide (it found its mate); filled by phase 1 (0xffff: void)
+  uint16_t ovl[kUnitCap];
 };
 struct NoExtra {};
 
@@ -231,7 +229,7 @@ struct __align__(16) BlockSharedT {
   uint4 seg[seg_cap<EXTRA>()];
   typename std::conditional<EXTRA, SegExtra, NoExtra>::type ex;
   uint16_t owner[kUnitCap];     // unit slot -> segment
-  unsigned long long n_alloc[2];  // segments << 32 | units handed out this round (by round parity)
+  unsigned long long n_alloc[2];  // segments << 32 | overlap-list entries << 16 | units handed out this round (by round parity)
   uint32_t more[2];               // a thread still has records of this window after this round (by round parity)
 };
 
@@ -358,7 +356,20 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
 // packed (segments << 32 | units) counter, so unit slots grow with the segment index.
 // Returns false for a lane whose segments did not fit this round (it got neither): the
 // caller keeps its cursor and retries next round.
-template <bool EXTRA>
+// Stitching: the units of a segment (window positions [s1, e1), first unit jlo) with positions
+// that the M op of the mate described by mi covers too, if this record is the one that decides
+// them (it found its mate in the table, pileup.go:409-430): first such unit relative to jlo, count.
+__device__ __forceinline__ uint32_t overlap_units(int32_t s1, int32_t e1, uint32_t jlo, const uint4& mi, uint32_t& first) {
+  first = 0;
+  if ((mi.y & 0x60000u) != 0x60000u) return 0u;  // has a mate, and found it
+  const int32_t ms = (int32_t)mi.x, me = ms + (int32_t)(mi.y & 0xffffu);
+  const int32_t lo = s1 > ms ? s1 : ms, hi = e1 < me ? e1 : me;
+  if (hi <= lo) return 0u;
+  first = ((uint32_t)lo >> 5) - jlo;
+  return (((uint32_t)(hi - 1) >> 5) - jlo) - first + 1u;
+}
+
+template <bool EXTRA, bool STITCH>
 __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
                                           const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
                                           uint32_t qdelta, uint32_t sslot, int32_t rec, uint32_t par, uint4 miA,
@@ -369,19 +380,26 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
   const bool realB = seg_extent(B, wlen, s1B, e1B, jloB, UB) && wantB;
   if (!realA) UA = 0;
   if (!realB) UB = 0;
-  const uint32_t nseg = (realA ? 1u : 0u) + (realB ? 1u : 0u), U = UA + UB;
-  // inclusive prefix sums of (segments, units) over the wave, packed as count << 16 | units
-  // (a wave adds at most 128 segments x kW/32 units: no carry between the fields)
-  const uint32_t mine = (nseg << 16) | U;
+  uint32_t fA = 0, fB = 0, nA = 0, nB = 0;  // stitch: entries of the overlap list
+  if constexpr (STITCH) {
+    if (realA) nA = overlap_units(s1A, e1A, jloA, miA, fA);
+    if (realB) nB = overlap_units(s1B, e1B, jloB, miB, fB);
+  }
+  const uint32_t nseg = (realA ? 1u : 0u) + (realB ? 1u : 0u), U = UA + UB, nov = nA + nB;
+  // inclusive prefix sums of (segments, list entries, units) over the wave, packed as
+  // segments << 23 | entries << 13 | units (a wave adds at most 128 segments, 128 x 6 entries
+  // and 128 x (kW/32 + 1) units: no carry between the fields)
+  const uint32_t mine = (nseg << 23) | (nov << 13) | U;
   const uint32_t incl = wave_inclusive_scan(mine);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   unsigned long long base = 0;
   if ((threadIdx.x & 63) == 0 && total != 0)
-    base = atomicAdd(&S.n_alloc[par], ((unsigned long long)(total >> 16) << 32) | (total & 0xffffu));
-  const uint32_t base_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    base = atomicAdd(&S.n_alloc[par], ((unsigned long long)(total >> 23) << 32) | (((total >> 13) & 0x3ffu) << 16) | (total & 0x1fffu));
+  const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
   const uint32_t base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
   const uint32_t excl = incl - mine;
-  const uint32_t idx = base_s + (excl >> 16), us = base_u + (excl & 0xffffu);
+  // (units and entries handed out in a round stay below 2^16 each: 512 lanes x 2 x 33)
+  const uint32_t idx = base_s + (excl >> 23), us = (base_lo & 0xffffu) + (excl & 0x1fffu);
   const bool ok = idx + nseg <= (uint32_t)seg_cap<EXTRA>() && us + U <= (uint32_t)kUnitCap;
   if (ok) {
     if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, qdelta, sslot, rec, miA, mxA);
@@ -389,6 +407,17 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
       write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, qdelta, sslot, rec, miB, mxB);
   } else {
     for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
+  }
+  if constexpr (STITCH) {
+    // every entry is one of the lane's units, so entries run behind unit slots: a lane whose
+    // units fit has room for its entries too
+    uint32_t o = (base_lo >> 16) + ((excl >> 13) & 0x3ffu);
+    if (ok) {
+      for (uint32_t i = 0; i < nA; i++) S.ex.ovl[o++] = (uint16_t)(us + fA + i);
+      for (uint32_t i = 0; i < nB; i++) S.ex.ovl[o++] = (uint16_t)(us + UA + fB + i);
+    } else {
+      for (uint32_t i = 0; i < nov && o < (uint32_t)kUnitCap; i++) S.ex.ovl[o++] = 0xffffu;
+    }
   }
   return ok;
 }
@@ -507,6 +536,167 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
     L.mq[0] = a0.x; L.mq[1] = a0.y; L.mq[2] = a0.z; L.mq[3] = a0.w;
     L.mq[4] = a1.x; L.mq[5] = a1.y; L.mq[6] = a1.z; L.mq[7] = a1.w;
     L.ms[0] = b0.x; L.ms[1] = b0.y; L.ms[2] = b0.z; L.ms[3] = b0.w;
+  }
+}
+
+// ---- stitching: the positions both mates cover (addReadPair, pileup.go:406-446)
+// Such positions are left out by the plain pass and decided here, 8 at a time: work item w of the
+// round's overlap list = group (w & 3) of the unit in entry (w >> 2).  A lane holds the 8 bases
+// and 8 quals of the record and of its mate over the group: 10 dwords in flight.
+struct OvGroup {
+  uint32_t x0, x1;        // own packed bases: dwords m, m+1 of the unit's 20 bytes
+  uint32_t q0, q1, q2;    // own quals: dwords 2m .. 2m+2 of the unit's 36 bytes
+  uint32_t m0, m1;        // the mate's bases over the same positions
+  uint32_t n0, n1, n2;    // ... and quals
+  uint32_t ovg;           // positions of the group to decide (8 bits); 0: nothing to do
+  uint32_t sh;            // 0..4 own nibble shift x 4 | 5..6 own qual byte shift | 8..12 mate nibble shift x 4 | 13..14 mate qual byte shift
+  uint32_t lds_off;       // byte offset in the planes of the group's position 0, strand slot included
+  uint32_t seg;
+  int32_t pw;             // window position of the group's first position
+};
+
+template <class SH>
+__device__ __forceinline__ void issue_ov_group(const KernelParams& P, const SH& S, uint32_t w, uint32_t n_ovl,
+                                               uint32_t T, uint32_t cpo, OvGroup& G) {
+  const uint32_t m = w & 3u;
+  uint32_t t = (w >> 2) < n_ovl ? (uint32_t)S.ex.ovl[w >> 2] : T;
+  bool in = t < T;
+  uint32_t s = S.owner[in ? t : 0];
+  if (s == 0xffffu) { in = false; s = 0; }
+  const uint4 r = S.seg[s];
+  const uint32_t u = t - (r.z & 0x7fffu);
+  const uint32_t jj = ((r.z >> 16) & 0x3fu) + u;
+  const uint32_t mask = (u == 0 ? 0xffffffffu << ((r.y >> 8) & 31u) : 0xffffffffu) &
+                        (u == ((r.y >> 24) & 0x3fu) ? 0xffffffffu >> (31u - ((r.y >> 13) & 31u)) : 0xffffffffu);
+  bool second = false;
+  const uint32_t ov = in ? mate_overlap(S, s, jj, second) & mask : 0u;
+  const uint32_t ovg = second ? (ov >> (8u * m)) & 0xffu : 0u;
+  G.ovg = ovg;
+  G.seg = s;
+  G.pw = (int32_t)((4u * jj + m) * 8u);
+  G.lds_off = (jj + cpo + ((r.y >> 6) & 1u) * (uint32_t)kStride + 8u * m * (uint32_t)kSub) * 4u;
+  // own bytes (see issue_unit): bases at off + 16u, quals at off + r.w + 32u
+  const uint64_t off = (((uint64_t)(r.y & 7u) << 32) | r.x) + 16u * u;
+  const uint8_t* sp = P.blob + (ovg ? off + 4u * m : 0);
+  const uint8_t* qp = P.blob + (ovg ? off + (int64_t)(int32_t)r.w + 16 * (int64_t)u + 8u * m : 0);
+  // the mate's: read index of the unit's position 0, then as for the record itself
+  const uint4 mi4 = S.ex.s_mate[s];
+  const uint32_t mx = S.ex.s_mx[s];
+  const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x + (int32_t)(mx & 0xffffu);
+  const int32_t mcig = (int32_t)((((mi4.w >> 16) + 1u) & ~1u) * 4);
+  const int32_t qo = (int32_t)((mx >> 16) * 8u) + mi0;  // may be < 0 by less than the buffer's leading pad
+  const int32_t so = mcig + (mi0 >> 1);
+  G.sh = (((r.y >> 3) & 7u) << 2) | (((r.z >> 24) & 3u) << 5) |
+         ((2u * ((uint32_t)so & 3u) + ((uint32_t)mi0 & 1u)) << 10) | (((uint32_t)qo & 3u) << 13);
+  const uint8_t* mb = P.blob + (ovg ? (uint64_t)mi4.z * 8 : 64);
+  const uint8_t* mqp = mb + (ovg ? (qo & ~3) + 8 * (int32_t)m : 0);
+  const uint8_t* msp = mb + (ovg ? (so & ~3) + 4 * (int32_t)m : 0);
+  const u32x2a a = *(const u32x2a*)sp;
+  const u32x3a b = *(const u32x3a*)qp;
+  const u32x2a c = *(const u32x2a*)msp;
+  const u32x3a d = *(const u32x3a*)mqp;
+  G.x0 = a.x; G.x1 = a.y;
+  G.q0 = b.x; G.q1 = b.y; G.q2 = b.z;
+  G.m0 = c.x; G.m1 = c.y;
+  G.n0 = d.x; G.n1 = d.y; G.n2 = d.z;
+}
+
+// Equal bases: the base if qualSumTable[q0][q1] >= minBaseQual (a per-row threshold, qthr), else
+// depth only; X stays X; different bases: X (pileup.go:409-430).
+template <bool CLIP, class SH>
+__device__ __forceinline__ void process_ov_group(const KernelParams& P, SH& B, const OvGroup& G) {
+  const uint32_t ovg = G.ovg;
+  if (!ovg) return;
+  constexpr uint32_t M1 = 0x11111111u, H = 0x80808080u;
+  const uint32_t sw = __builtin_amdgcn_alignbit(G.x1, G.x0, G.sh & 0x1cu);
+  const uint32_t qsh = (G.sh >> 5) & 3u;
+  const uint32_t qlo = __builtin_amdgcn_alignbyte(G.q1, G.q0, qsh), qhi = __builtin_amdgcn_alignbyte(G.q2, G.q1, qsh);
+  const uint32_t msw = __builtin_amdgcn_alignbit(G.m1, G.m0, (G.sh >> 8) & 0x1cu);
+  const uint32_t msh = (G.sh >> 13) & 3u;
+  const uint32_t mqlo = __builtin_amdgcn_alignbyte(G.n1, G.n0, msh), mqhi = __builtin_amdgcn_alignbyte(G.n2, G.n1, msh);
+  // plane codes of the record's bases (Seq8ToEnumTable: one-hot nibble -> log2, anything else X = 4)
+  const uint32_t t1 = sw >> 1;
+  const uint32_t lg = (t1 & 0x77777777u) - ((sw >> 3) & M1);
+  const uint32_t xx = sw ^ t1, a = sw & t1;
+  const uint32_t oh = (xx ^ (xx >> 2)) & ~(a | (a >> 2)) & M1;
+  const uint32_t oh3 = oh | (oh << 1);
+  const uint32_t cpass = (lg & oh3) + ((oh ^ M1) << 2);
+  const uint32_t cf = 0x44444444u | oh;  // failing: base -> depth-only (5), X stays X (4)
+  // nibble k of dn != 0 <=> the reads disagree at position k
+  const uint32_t dn = msw ^ sw;
+  const uint32_t eqn = ~(dn | (dn >> 1) | (dn >> 2) | (dn >> 3)) & M1;
+  uint32_t ovn = (ovg | (ovg << 12)) & 0x000f000fu;  // 8 bits -> one flag per nibble
+  ovn = (ovn | (ovn << 6)) & 0x03030303u;
+  ovn = (ovn | (ovn << 3)) & M1;
+  uint32_t cw = 0x44444444u, vmask = ovg;
+  bool fast = !CLIP;
+  if constexpr (!CLIP) {
+    // a qual >= 96 at an agreeing position indexes qualPassTable out of range (a Go runtime
+    // panic in the reference): those groups take the per-base loop below
+    uint32_t blo = ((((qlo & 0x7f7f7f7fu) + 0x20202020u) | qlo) | (((mqlo & 0x7f7f7f7fu) + 0x20202020u) | mqlo)) & H;
+    uint32_t bhi = ((((qhi & 0x7f7f7f7fu) + 0x20202020u) | qhi) | (((mqhi & 0x7f7f7f7fu) + 0x20202020u) | mqhi)) & H;
+    blo = (blo | (blo >> 4)) & 0x08800880u;
+    blo = (blo | (blo >> 8)) & 0x00088880u;
+    bhi = (bhi | (bhi >> 4)) & 0x08800880u;
+    bhi = (bhi | (bhi >> 8)) & 0x00088880u;
+    fast = ((((blo >> 7) | (bhi << 9)) & eqn & ovn) == 0);
+  }
+  if (fast) {
+    // the pair passes iff mate qual >= qthr[own qual] (qualSumTable row, qual.go:35-77): 8 byte
+    // lookups, then a SWAR byte compare
+    const uint8_t* const qt = B.ex.qthr;
+    const uint32_t tlo = (uint32_t)qt[qlo & 0xffu] | ((uint32_t)qt[(qlo >> 8) & 0xffu] << 8) |
+                         ((uint32_t)qt[(qlo >> 16) & 0xffu] << 16) | ((uint32_t)qt[qlo >> 24] << 24);
+    const uint32_t thi = (uint32_t)qt[qhi & 0xffu] | ((uint32_t)qt[(qhi >> 8) & 0xffu] << 8) |
+                         ((uint32_t)qt[(qhi >> 16) & 0xffu] << 16) | ((uint32_t)qt[qhi >> 24] << 24);
+    // (thresholds <= 96; the mask keeps a stray lookup of a qual >= 96 at a position that does
+    // not matter from borrowing into its neighbour)
+    uint32_t plo = ((mqlo | H) - (tlo & 0x7f7f7f7fu)) & H;
+    uint32_t phi = ((mqhi | H) - (thi & 0x7f7f7f7fu)) & H;
+    plo = (plo | (plo >> 4)) & 0x08800880u;
+    plo = (plo | (plo >> 8)) & 0x00088880u;
+    phi = (phi | (phi >> 4)) & 0x08800880u;
+    phi = (phi | (phi >> 8)) & 0x00088880u;
+    const uint32_t p2 = (plo >> 7) | (phi << 9);
+    const uint32_t p15 = (p2 << 4) - p2, eq15 = (eqn << 4) - eqn;
+    cw = (eq15 & ((cpass & p15) | (cf & ~p15))) | (~eq15 & 0x44444444u);
+  } else {
+    const uint32_t sg = G.seg;
+    int32_t b0 = 0, lseq = 0;
+    if constexpr (CLIP) {  // clipQuals (pileup_support.go:51-69) on both reads
+      b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + (G.pw - B.ex.s_ref[sg]);
+      lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
+    }
+    const uint4 mi4 = B.ex.s_mate[sg];
+    const int32_t mls = (int32_t)(mi4.w & 0xffffu);
+    const int32_t mi0 = G.pw - (int32_t)mi4.x + (int32_t)(B.ex.s_mx[sg] & 0xffffu);
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+      if (!((ovg >> k) & 1u)) continue;
+      uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
+      uint32_t mq = ((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu;
+      if constexpr (CLIP) {
+        q = clipped_qual(q, b0 + k, lseq, P.clip);
+        mq = clipped_qual(mq, mi0 + k, mls, P.clip);
+      }
+      uint32_t code = 4u;  // the reads disagree: X
+      if ((eqn >> (4 * k)) & 1u) {
+        if (q >= 96u || mq >= 96u) {
+          atomicMin(&P.err->read, B.ex.s_rec[sg]);
+          vmask &= ~(1u << k);
+          continue;
+        }
+        code = ((mq >= (uint32_t)B.ex.qthr[q] ? cpass : cf) >> (4 * k)) & 7u;
+      }
+      cw = (cw & ~(0xfu << (4 * k))) | (code << (4 * k));
+    }
+  }
+  char* const lds = (char*)B.cnt;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t c = (cw >> (4 * k)) & 7u;
+    const uint32_t val = (vmask >> k) & 1u;
+    atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + G.lds_off + k * kSub * 4), val);
   }
 }
 
@@ -755,6 +945,26 @@ __device__ __forceinline__ bool next_piece(const uint32_t* cg, uint32_t cg0, uin
   return true;
 }
 
+// Block-uniform values that come from global memory arrive through vector loads (the kernel also
+// stores to global memory, so the compiler will not use the scalar cache for them) and would sit
+// in a VGPR of every lane for the whole window: move them to SGPRs - when the window starts, not
+// where they are fetched (a readfirstlane has to wait for its load).
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ Window uni_window(const Window& v) {
+  Window w;
+  w.ref_id = uni(v.ref_id);
+  w.g0 = uni(v.g0);
+  w.g1 = uni(v.g1);
+  w.iv_lo = (uint32_t)uni((int32_t)v.iv_lo);
+  w.iv_hi = (uint32_t)uni((int32_t)v.iv_hi);
+  w.full = uni(v.full);
+  w.n_rows = uni(v.n_rows);
+  w.pad = 0;
+  w.row_base = (int64_t)(((uint64_t)(uint32_t)uni((int32_t)((uint64_t)v.row_base >> 32)) << 32) |
+                         (uint32_t)uni((int32_t)(uint32_t)v.row_base));
+  return w;
+}
+
 // Workgroup = kWinPerBlock consecutive windows, processed one after the other:
 //   phase 1  thread = record: read filters, CIGAR -> M-segments clipped to the window
 //   phase 2  thread = unit:   counts into the LDS planes
@@ -833,8 +1043,8 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   }
 
   for (uint32_t item = w_first; item < w_last; item += DEEP ? gridDim.x : 1u) {
-    const Window win = n_win;
-    const int32_t r0 = n_r0, r1 = n_r1;
+    const Window win = uni_window(n_win);
+    const int32_t r0 = uni(n_r0), r1 = uni(n_r1);
     const int32_t g0 = win.g0, g1 = win.g1;
     const uint32_t wlen = (uint32_t)(g1 - g0);
     // A short window (a panel target) leaves most columns of the planes unused, and at depth
@@ -988,7 +1198,21 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     constexpr bool LATE = STITCH;
     [[maybe_unused]] bool first_round = true;
     if constexpr (LATE) {
+#if defined(BP_EXP_NOPF)
+      if (rec < r1) {
+        const uint4* cp = (const uint4*)(P.cores + rec);
+        decode(cp[0], cp[1], ((const uint4*)P.mate)[rec]);
+      }
+#elif defined(BP_EXP_SLIMPF)
+      if (rec < r1) {
+        const uint4* cp = (const uint4*)(P.cores + rec);
+        uint4 me = make_uint4(pme.x, 0, 0, 0);
+        if (pme.x & MATE_HAS) me = ((const uint4*)P.mate)[rec];
+        decode(pc0, cp[1], me);
+      }
+#else
       if (rec < r1) decode(pc0, pc1, pme);
+#endif
     }
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
     [[maybe_unused]] uint4 nme = nc0;
@@ -1062,7 +1286,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         }
         if (!__any(wantA)) break;
-        const bool ok = emit_wave(S, wantA, A, wantB, B, wlen, blob, lseqnc, qdelta, sslot, rec, par, miA, mxA, miB, mxB);
+        const bool ok = emit_wave<EXTRA, STITCH>(S, wantA, A, wantB, B, wlen, blob, lseqnc, qdelta, sslot, rec, par, miA, mxA, miB, mxB);
         if (wantA) {
           if (!ok) {
             failed = true;
@@ -1098,38 +1322,61 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 
       // ---- prefetch for the next window: everything it needs from global memory before its
       // unit loads (window descriptor, record range two ahead, this thread's first record core)
-      // is fetched while this window is in phase 2 and flushed
-      if (LATE ? last : !next_issued) {
-        next_issued = true;
-        if constexpr (DEEP) {
-          if (item + gridDim.x < w_last) {
-            const uint4 it = P.extra_items[item + gridDim.x];
-            n_win = P.windows[it.x];
-            n_r0 = (int32_t)it.y;
-            n_r1 = (int32_t)it.z;
+      // is fetched while this window is in phase 2 and flushed.  LATE: behind phase 2, when the
+      // units' registers are free again (issued before it, the compiler parks the 12 dwords in
+      // scratch, and the store has to wait for the load: the whole latency at the head of phase 2)
+      auto prefetch_next = [&]() {
+        if (LATE ? last : !next_issued) {
+          next_issued = true;
+          if constexpr (DEEP) {
+            if (item + gridDim.x < w_last) {
+              const uint4 it = P.extra_items[item + gridDim.x];
+              n_win = P.windows[it.x];
+              n_r0 = (int32_t)it.y;
+              n_r1 = (int32_t)it.z;
+              if constexpr (LATE) {  // (no registers to hold them in until the window starts)
+                n_win = uni_window(n_win);
+                n_r0 = uni(n_r0);
+                n_r1 = uni(n_r1);
+              }
+              if (n_r0 + tid < n_r1) {
+                const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
+                nc0 = cp[0];
+                nc1 = cp[1];
+                if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
+              }
+            }
+          } else if (item + 1 < w_last) {
+            n_r0 = nn_r0;
+            n_r1 = nn_r1;
+            n_win = P.windows[item + 1];
+            if constexpr (LATE) n_win = uni_window(n_win);
             if (n_r0 + tid < n_r1) {
               const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
+#if defined(BP_EXP_NOPF)
+              if constexpr (!LATE) { nc0 = cp[0]; nc1 = cp[1]; }
+#elif defined(BP_EXP_SLIMPF)
+              nc0 = cp[0];
+              if constexpr (!LATE) nc1 = cp[1];
+              if constexpr (STITCH) nme.x = ((const uint32_t*)P.mate)[4 * (n_r0 + tid)];
+#else
               nc0 = cp[0];
               nc1 = cp[1];
               if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
+#endif
+            }
+            if (item + 2 < w_last) {
+              nn_r0 = P.win_r0[item + 2];
+              nn_r1 = P.win_r1[item + 2];
+              if constexpr (LATE) {
+                nn_r0 = uni(nn_r0);
+                nn_r1 = uni(nn_r1);
+              }
             }
           }
-        } else if (item + 1 < w_last) {
-          n_r0 = nn_r0;
-          n_r1 = nn_r1;
-          n_win = P.windows[item + 1];
-          if (n_r0 + tid < n_r1) {
-            const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
-            nc0 = cp[0];
-            nc1 = cp[1];
-            if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
-          }
-          if (item + 2 < w_last) {
-            nn_r0 = P.win_r0[item + 2];
-            nn_r1 = P.win_r1[item + 2];
-          }
         }
-      }
+      };
+      if constexpr (!LATE) prefetch_next();
 
       // ---- phase 2: thread = unit (32 window positions of one segment); kDepth units in
       // flight per lane
@@ -1138,7 +1385,8 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         S.more[par ^ 1u] = 0;
       }
       const uint32_t n_alloc_u = (uint32_t)S.n_alloc[par];
-      const uint32_t T = n_alloc_u < (uint32_t)kUnitCap ? n_alloc_u : (uint32_t)kUnitCap;
+      const uint32_t T = (n_alloc_u & 0xffffu) < (uint32_t)kUnitCap ? (n_alloc_u & 0xffffu) : (uint32_t)kUnitCap;
+      [[maybe_unused]] const uint32_t n_ovl = (n_alloc_u >> 16) < (uint32_t)kUnitCap ? (n_alloc_u >> 16) : (uint32_t)kUnitCap;
 #ifdef BP_STAMPS_P2
       const uint32_t wbase = (uint32_t)tid & ~63u;
 #endif
@@ -1178,38 +1426,53 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // flight; at 30x a window is 2-3 units per thread and the loop body rarely runs.
         // (with -clip one unit in flight: 6.40 -> 5.97 ms on chr1 30x; the clip masks' registers
         // are what a second unit's loads would have to live next to)
-        // Stitched runs make two passes.  The first takes every unit through the plain path with
+        // Stitched runs treat a unit in two parts.  Every unit goes through the plain path with
         // the quality rule, leaving out the positions the record's mate covers too (Depth++ once
-        // per pair position, pileup.go:409-430); a unit whose record has to decide such positions
-        // (it found its mate in the table) is noted in the wave's list.  The second pass takes
-        // only the listed units - few at whole-genome insert sizes - loads the mate's bases and
-        // quals next to the record's own and counts just those positions (process_unit_plain's
-        // stitched branch).  So the bulk of the units runs at the plain path's depth and register
-        // budget, and the mate's loads are issued only where they are used.
+        // per pair position, pileup.go:409-430).  The units whose record has to decide such
+        // positions (it found its mate in the table) were listed by phase 1 - few at whole-genome
+        // insert sizes; for them the mate's bases and quals are loaded next to the record's own
+        // and just those positions are counted (process_unit_plain's stitched branch).  That
+        // comes FIRST, its loads issued together with the first plain unit's: the round trip is
+        // shared.  So the bulk of the units runs at the plain path's depth and register budget,
+        // and the mate's loads are issued only where they are used.
         constexpr int kD = NEED_Q ? (CLIP ? 1 : kDepthQ) : kDepth;
         const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
         const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
         UnitLoad<NEED_Q, false> L[kD];
         uint32_t t = (uint32_t)tid;
-        uint32_t n_ov = 0;  // wave-uniform
-        [[maybe_unused]] const uint32_t lane = (uint32_t)tid & 63u, wv = (uint32_t)tid >> 6;
         auto issue1 = [&](UnitLoad<NEED_Q, false>& U, uint32_t tt) {
           issue_unit<NEED_Q, false>(P, S, slot_of(tt, T, R), T, U);
           if constexpr (STITCH) {
             bool second = false;
-            const bool in = (U.meta & 0x10000u) != 0;
-            const uint32_t ov = in ? mate_overlap(S, U.seg, U.meta & 0x3fu, second) & U.mask : 0u;
-            U.mask &= ~ov;
-            const unsigned long long b = __builtin_amdgcn_ballot_w64(second && ov != 0);
-            if (second && ov != 0) {
-              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-              S.ex.ovl[wv][n_ov + rank] = (uint8_t)((((tt - (uint32_t)tid) / kBlock) << 6) | lane);
-            }
-            n_ov += (uint32_t)__builtin_popcountll(b);
+            if (U.meta & 0x10000u) U.mask &= ~mate_overlap(S, U.seg, U.meta & 0x3fu, second);
           }
         };
+        if constexpr (STITCH) {
+#ifdef BP_EXP_NO2B
+          const uint32_t n_ovl_ = 0;
+#else
+          const uint32_t n_ovl_ = n_ovl;
+#endif
+          if (n_ovl_ != 0) {  // block-uniform
+            OvGroup G;
+            issue_ov_group(P, S, (uint32_t)tid, n_ovl_, T, cpo, G);
+            issue1(L[0], t);
+            t += kBlock;
+            process_ov_group<CLIP>(P, S, G);
+            for (uint32_t w = (uint32_t)tid + kBlock; w - (uint32_t)tid < 4u * n_ovl_; w += kBlock) {  // deep windows only
+              issue_ov_group(P, S, w, n_ovl_, T, cpo, G);
+              process_ov_group<CLIP>(P, S, G);
+            }
+          } else {
+            issue1(L[0], t);
+            t += kBlock;
+          }
+        } else {
+          issue1(L[0], t);
+          t += kBlock;
+        }
 #pragma unroll
-        for (int d = 0; d < kD; d++) {
+        for (int d = 1; d < kD; d++) {
           issue1(L[d], t);
           t += kBlock;
         }
@@ -1226,27 +1489,9 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 #pragma unroll
         for (int d = 0; d < kD; d++)
           if ((uint32_t)d < rem) unit<false, CLIP, MINQ0>(P, S, L[d], cpo);
-#ifdef BP_EXP_NO2B_CT
-        if constexpr (false) {
-#else
-        if constexpr (STITCH) {
-#endif
-          __builtin_amdgcn_wave_barrier();  // the list is the wave's own: written above, read below
-#ifdef BP_EXP_NO2B
-          n_ov = 0;
-#endif
-          for (uint32_t b0 = 0; b0 < n_ov; b0 += 64) {
-            const bool in = b0 + lane < n_ov;
-            const uint32_t e = in ? S.ex.ovl[wv][b0 + lane] : 0u;
-            const uint32_t tt = ((uint32_t)tid & ~63u) + (e & 63u) + (e >> 6) * kBlock;
-            UnitLoad<true, true> M;
-            issue_unit<true, true>(P, S, in ? slot_of(tt, T, R) : T, T, M);
-            M.mask = M.ov32;  // everything else was counted in the first pass
-            unit<true, CLIP, false>(P, S, M, cpo);
-          }
-        }
       }
 #endif
+      if constexpr (LATE) prefetch_next();
       BP_STAMP(4);
       par ^= 1u;
       if constexpr (LATE) __syncthreads();

@@ -432,11 +432,6 @@ struct UnitLoad {
   uint32_t meta;                   // 0..5 window unit | 6..8 nibble shift | 9..10 qual byte shift |
                                    // 11 strand slot | 16 active
   uint32_t seg;                    // segment (stitched / clipped paths)
-  // stitch, mate that is one M op, this record being the one that found its mate: the mate's
-  // quals and bases over the same 32 positions, and which of them the mate covers
-  uint32_t mq[STITCH ? 9 : 1], ms[STITCH ? 5 : 1];
-  uint32_t ov32;
-  uint32_t msh;                    // 0..1 mate qual byte shift | 2..6 4 * mate nibble shift
 };
 
 // Loads are issued unconditionally (inactive lanes read the start of the payload buffer) so
@@ -504,39 +499,6 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
   const u32x4a s0 = *(const u32x4a*)sp;
   L.sd[4] = *(const uint32_t*)(sp + 16);
   L.sd[0] = s0.x; L.sd[1] = s0.y; L.sd[2] = s0.z; L.sd[3] = s0.w;
-  if constexpr (STITCH) {
-    // For a mate that is one M op the positions both reads cover are a range of the unit: the
-    // record stored first simply drops them (pileup.go:409-430: Depth++ once, by the record
-    // that found its mate); that one fetches the mate's quals and bases over the unit now,
-    // with the same wide loads as its own.
-    const uint4 mi4 = S.ex.s_mate[s];
-    bool second;
-    uint32_t ov = in ? mate_overlap(S, s, jj, second) : 0u;
-    second = (mi4.y & 0x20000u) != 0;
-    // mate read index of the unit's position 0
-    const uint32_t mx = S.ex.s_mx[s];
-    const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x + (int32_t)(mx & 0xffffu);
-    if (!second) { L.mask &= ~ov; ov = 0; }
-    ov &= L.mask;
-    L.ov32 = ov;
-    L.meta |= second ? 0x40000u : 0u;
-    const uint32_t mlseqnc = mi4.w;
-    const int32_t mcig = (int32_t)((((mlseqnc >> 16) + 1u) & ~1u) * 4);
-    const int32_t qo = (int32_t)((mx >> 16) * 8u) + mi0;  // >= -23: the payload buffer starts with a pad
-    const int32_t so = mcig + (mi0 >> 1);
-    L.msh = ((uint32_t)qo & 3u) | ((2u * ((uint32_t)so & 3u) + ((uint32_t)mi0 & 1u)) << 4);
-    const uint8_t* mb = P.blob + (ov ? (uint64_t)mi4.z * 8 : 64);
-    const uint8_t* mqp = mb + (ov ? (qo & ~3) : 0);
-    const uint8_t* msp = mb + (ov ? (so & ~3) : 0);
-    const u32x4a a0 = *(const u32x4a*)mqp;
-    const u32x4a a1 = *(const u32x4a*)(mqp + 16);
-    L.mq[8] = *(const uint32_t*)(mqp + 32);
-    const u32x4a b0 = *(const u32x4a*)msp;
-    L.ms[4] = *(const uint32_t*)(msp + 16);
-    L.mq[0] = a0.x; L.mq[1] = a0.y; L.mq[2] = a0.z; L.mq[3] = a0.w;
-    L.mq[4] = a1.x; L.mq[5] = a1.y; L.mq[6] = a1.z; L.mq[7] = a1.w;
-    L.ms[0] = b0.x; L.ms[1] = b0.y; L.ms[2] = b0.z; L.ms[3] = b0.w;
-  }
 }
 
 // ---- stitching: the positions both mates cover (addReadPair, pileup.go:406-446)
@@ -720,7 +682,6 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B,
   const uint32_t meta = L.meta;
   const uint32_t jj = meta & 0x3fu;
   uint32_t vmask = L.mask;  // positions still to be counted
-  const uint32_t ov32 = L.ov32;
   const uint32_t* const x = L.sd;  // base k of a dword at bits 4k (the packer stores it that way)
   const uint32_t nsh = (meta >> 4) & 0x1cu;  // 4 * nibble shift
   const uint32_t cbase = (jj + cpo + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
@@ -750,6 +711,9 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B,
       mhi = (mhi | (mhi >> 4)) & 0x08800880u;
       mhi = (mhi | (mhi >> 8)) & 0x00088880u;
       uint32_t pn = (mlo >> 7) | (mhi << 9);  // bit 4k = base k passes
+      // (tried: even/odd quals gathered with v_perm so that the byte flags fall on the nibbles
+      // directly, 5 % fewer VALU instructions in all; 3 % slower on chr1 30x -min-base-qual 20:
+      // the time went to waits, not to issue)
       if constexpr (CLIP) {
         // clipQuals (pileup_support.go:51-69): the first and last `clip` bases of the read
         // have quality 2
@@ -769,92 +733,7 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B,
       }
       const uint32_t pn15 = (pn << 4) - pn;     // 0xf per passing base
       const uint32_t cf = 0x44444444u | oh;     // failing: base -> depth-only (5), X stays X (4)
-      const uint32_t cpass = cw;
       cw = (cw & pn15) | (cf & ~pn15);
-      if constexpr (STITCH) {
-        // positions of this group that the mate covers too (pileup.go:409-430); only the
-        // record that found its mate has any (the other one dropped them at issue time)
-        const uint32_t ovg = ((ov32 & vmask) >> (8 * m)) & 0xffu;
-        if (ovg) {
-          const uint32_t mqlo = __builtin_amdgcn_alignbyte(L.mq[2 * m + 1], L.mq[2 * m], L.msh & 3u);
-          const uint32_t mqhi = __builtin_amdgcn_alignbyte(L.mq[2 * m + 2], L.mq[2 * m + 1], L.msh & 3u);
-          const uint32_t msw = __builtin_amdgcn_alignbit(L.ms[m + 1], L.ms[m], (L.msh >> 2) & 0x1cu);
-          // nibble k of dn != 0 <=> the reads disagree at position k
-          const uint32_t dn = msw ^ sw;
-          const uint32_t eqn = ~(dn | (dn >> 1) | (dn >> 2) | (dn >> 3)) & M1;
-          // 8 overlap bits -> one flag per nibble
-          uint32_t ovn = (ovg | (ovg << 12)) & 0x000f000fu;
-          ovn = (ovn | (ovn << 6)) & 0x03030303u;
-          ovn = (ovn | (ovn << 3)) & M1;
-          bool fast = !CLIP;
-          if constexpr (!CLIP) {
-            // a qual >= 96 at an agreeing position indexes qualPassTable out of range (a Go
-            // runtime panic in the reference): those groups take the per-base loop below
-            uint32_t blo = ((((qlo & 0x7f7f7f7fu) + 0x20202020u) | qlo) | (((mqlo & 0x7f7f7f7fu) + 0x20202020u) | mqlo)) & H;
-            uint32_t bhi = ((((qhi & 0x7f7f7f7fu) + 0x20202020u) | qhi) | (((mqhi & 0x7f7f7f7fu) + 0x20202020u) | mqhi)) & H;
-            blo = (blo | (blo >> 4)) & 0x08800880u;
-            blo = (blo | (blo >> 8)) & 0x00088880u;
-            bhi = (bhi | (bhi >> 4)) & 0x08800880u;
-            bhi = (bhi | (bhi >> 8)) & 0x00088880u;
-            fast = ((((blo >> 7) | (bhi << 9)) & eqn & ovn) == 0);
-          }
-          if (fast) {
-            // the pair passes iff mate qual >= qthr[own qual] (qualSumTable row, qual.go:35-77):
-            // 8 byte lookups, then the same byte compare as the single-read rule
-            const uint8_t* const qt = B.ex.qthr;
-            const uint32_t tlo = (uint32_t)qt[qlo & 0xffu] | ((uint32_t)qt[(qlo >> 8) & 0xffu] << 8) |
-                                 ((uint32_t)qt[(qlo >> 16) & 0xffu] << 16) | ((uint32_t)qt[qlo >> 24] << 24);
-            const uint32_t thi = (uint32_t)qt[qhi & 0xffu] | ((uint32_t)qt[(qhi >> 8) & 0xffu] << 8) |
-                                 ((uint32_t)qt[(qhi >> 16) & 0xffu] << 16) | ((uint32_t)qt[qhi >> 24] << 24);
-            // (thresholds <= 96; the mask keeps a stray lookup of a qual >= 96 at a position that
-            // does not matter from borrowing into its neighbour)
-            uint32_t plo = ((mqlo | H) - (tlo & 0x7f7f7f7fu)) & H;
-            uint32_t phi = ((mqhi | H) - (thi & 0x7f7f7f7fu)) & H;
-            plo = (plo | (plo >> 4)) & 0x08800880u;
-            plo = (plo | (plo >> 8)) & 0x00088880u;
-            phi = (phi | (phi >> 4)) & 0x08800880u;
-            phi = (phi | (phi >> 8)) & 0x00088880u;
-            const uint32_t p2 = (plo >> 7) | (phi << 9);
-            const uint32_t p15 = (p2 << 4) - p2, eq15 = (eqn << 4) - eqn, ov15 = (ovn << 4) - ovn;
-            // agree: the base if the pair passes, else depth only (X stays X); disagree: X
-            const uint32_t both = (eq15 & ((cpass & p15) | (cf & ~p15))) | (~eq15 & 0x44444444u);
-            cw = (cw & ~ov15) | (both & ov15);
-          } else {
-            const int32_t Pw = (int32_t)((4 * jj + m) * 8);
-            const uint32_t sg = L.seg;
-            int32_t b0 = 0, lseq = 0;
-            if constexpr (CLIP) {  // own clipped quals are needed again
-              b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + (Pw - B.ex.s_ref[sg]);
-              lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
-            }
-            const uint4 mi4 = B.ex.s_mate[sg];
-            const int32_t mls = (int32_t)(mi4.w & 0xffffu);
-            const int32_t mi0 = Pw - (int32_t)mi4.x + (int32_t)(B.ex.s_mx[sg] & 0xffffu);
-            // (rare, so one rolled copy: unrolled it bloated the kernel past the instruction
-            // cache and cost 4x)
-#pragma unroll 1
-            for (int k = 0; k < 8; k++) {
-              if (!((ovg >> k) & 1u)) continue;
-              uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
-              uint32_t mq = ((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu;
-              if constexpr (CLIP) {
-                q = clipped_qual(q, b0 + k, lseq, P.clip);
-                mq = clipped_qual(mq, mi0 + k, mls, P.clip);
-              }
-              uint32_t code = 4u;  // the reads disagree: X
-              if ((eqn >> (4 * k)) & 1u) {
-                if (q >= 96u || mq >= 96u) {
-                  atomicMin(&P.err->read, B.ex.s_rec[sg]);
-                  vmask &= ~(1u << (8 * m + k));
-                  continue;
-                }
-                code = ((mq >= (uint32_t)B.ex.qthr[q] ? cpass : cf) >> (4 * k)) & 7u;
-              }
-              cw = (cw & ~(0xfu << (4 * k))) | (code << (4 * k));
-            }
-          }
-        }
-      }
     }
     // lanes without a unit (or without a valid base in this group) sit the atomics out:
     // they would all add 0 to one address and serialise the whole instruction

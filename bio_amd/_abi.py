@@ -65,7 +65,7 @@ class bp_timing(C.Structure):
 
 
 EXPORTS = [
-    "bp_init", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute", "bp_compute_static",
+    "bp_init", "bp_device_count", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute", "bp_compute_static",
     "bp_num_rows", "bp_rows", "bp_rows_device", "bp_rows_export", "bp_rows_accumulate", "bp_rows_export_async", "bp_rows_accumulate_async", "bp_stream", "bp_column_sums", "bp_get_timing",
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
@@ -102,6 +102,7 @@ class bio_pileup_opts(C.Structure):
         ("stitch", C.c_int32),
         ("temp_dir", C.c_char_p),
         ("device", C.c_int32),
+        ("devices", C.c_int32),
     ]
 
 

@@ -181,6 +181,10 @@ struct Opts {  // snp.Opts / snp.DefaultOpts (pileup/snp/pileup.go:36-68)
   bool Stitch = false;
   std::string TempDir;
   int Device = 0;  // HIP device ordinal (no counterpart in the reference)
+  // Jobs are spread over this many logical devices, mapped round-robin onto the physical ones
+  // (-1: one per physical device; 0: everything on Device).  The reference's -parallelism with
+  // devices for goroutines (pileup.go:862-932).
+  int Devices = 0;
 };
 
 // Column-set bits (pileup.go:134-157) and pileup.ParseCols (pileup/common.go:118-166).

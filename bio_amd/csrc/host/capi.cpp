@@ -64,6 +64,7 @@ int bio_pileup_run(const char* xampath, const char* fapath, const char* format, 
   o.Stitch = opts->stitch != 0;
   o.TempDir = Str(opts->temp_dir);
   o.Device = opts->device;
+  o.Devices = opts->devices;
   std::string e = bio::Pileup(xampath, fapath, format, out_prefix, o);
   return e.empty() ? Ok(err, errlen) : Fail(e, err, errlen);
 }

@@ -51,7 +51,7 @@ bool ParseGoBool(const std::string& s, bool* out) {
 
 int BioPileupMain(int argc, char** argv) {
   Opts o;
-  std::string format = "tsv", out_prefix = "bio-pileup";
+  std::string format = "tsv", out_prefix = "bio-pileup", devices;
   const Flag flags[] = {
       {"bed", Flag::kString, &o.BedPath, "Input BED path; this xor -region required"},
       {"region", Flag::kString, &o.Region,
@@ -78,6 +78,7 @@ int BioPileupMain(int argc, char** argv) {
       {"stitch", Flag::kBool, &o.Stitch, "Stitch read-pairs"},
       {"temp-dir", Flag::kString, &o.TempDir, "Accepted for compatibility; no temporary files are written"},
       {"device", Flag::kInt, &o.Device, "HIP device ordinal"},
+      {"devices", Flag::kString, &devices, "Spread the jobs over this many devices (a number, mapped round-robin onto the GPUs present, or 'all'); default: only -device"},
   };
   auto usage = [&]() {
     printf("Usage: %s [OPTIONS] {b,p}ampath fapath\n", argv[0]);
@@ -158,6 +159,19 @@ int BioPileupMain(int argc, char** argv) {
               "'%s'\n",
               joined.c_str());
     return 1;
+  }
+  if (!devices.empty()) {
+    if (devices == "all") {
+      o.Devices = -1;
+    } else {
+      char* end = nullptr;
+      const long n = strtol(devices.c_str(), &end, 10);
+      if (*end || n < 1 || n > 1024) {
+        fprintf(stderr, "invalid value \"%s\" for flag -devices: a number from 1 to 1024, or all\n", devices.c_str());
+        return 2;
+      }
+      o.Devices = (int)n;
+    }
   }
   std::string err = Pileup(argv[i], argv[i + 1], format, out_prefix, o);
   if (!err.empty()) {

@@ -98,6 +98,7 @@ double Now() {
 struct Job {
   int ref;
   PosType start, end;  // positions [start, end) of contig `ref`
+  int64_t seq = 0;     // its place in the output order
 };
 
 // What closing a job needs besides its handles.
@@ -226,6 +227,15 @@ class Driver {
 
   void SetPadding(int64_t bed_pad) { bed_pad_ = bed_pad; }
 
+  // -devices: job k runs on logical device k mod N, logical devices mapped round-robin onto the
+  // physical ones - the reference's traverse.Each(parallelism, ...) (pileup.go:862-932) with
+  // devices for goroutines; jobs are independent (halo-padded), nothing crosses between devices.
+  std::vector<int> devices;  // physical ordinal of every logical device; empty: opts.Device only
+  int DeviceFor(int64_t seq) const {
+    return devices.empty() ? opts_.Device : devices[(size_t)(seq % (int64_t)devices.size())];
+  }
+  size_t n_closers() const { return devices.empty() ? 1 : devices.size(); }
+
   std::string OpenJob(const Job& j) {
     BEDUnion part = bed_.Subset(j.ref, (PosType)std::max<int64_t>(0, (int64_t)j.start - bed_pad_), j.ref,
                                 (PosType)std::min<int64_t>(kPosTypeMax, (int64_t)j.end + bed_pad_));
@@ -243,7 +253,7 @@ class Driver {
       bo.stitch = opts_.Stitch;
       bo.ignore_strand = ignore_strand_;
       bo.strand_req = s.strand_req;
-      bo.device = opts_.Device;
+      bo.device = DeviceFor(j.seq);
       if (bp_create(&bo, (int32_t)hd_.ref_lens.size(), hd_.ref_lens.data(), names.data(), &s.h) != BP_OK)
         return HandleErr(nullptr);
       const std::vector<PosType>& e = part.id_map[(size_t)j.ref];
@@ -283,7 +293,7 @@ class Driver {
   }
 
   // The handles of the open job leave the streams (the next job opens its own) and are closed
-  // by FinishJob, on the closer thread.
+  // by its device's closer thread.
   std::vector<bp_handle*> TakeHandles() {
     std::vector<bp_handle*> hs;
     for (Stream& s : streams) {
@@ -295,13 +305,23 @@ class Driver {
 
   // finishRef + the output conversion for one job (pileup.go:934-966): rows to the writers, in
   // job order.  Frees the handles.
-  std::string FinishJob(const Job& j, std::vector<bp_handle*>& hs, const JobRows& jr) {
-    std::string err = jr.device_text ? FinishJobText(hs, jr) : FinishJobRows(j, hs);
+  // First half, concurrent across devices: the device computation of the job.
+  std::string ComputeJob(std::vector<bp_handle*>& hs) {
+    for (bp_handle* h : hs) {
+      if (bp_finish(h) != BP_OK) return HandleErr(h);
+      if (per_read && bp_per_read_build(h) != BP_OK) return HandleErr(h);
+    }
+    return "";
+  }
+  // Second half, in job order: the rows (or the device's text) to the writers.
+  std::string OutputJob(const Job& j, std::vector<bp_handle*>& hs, const JobRows& jr) {
+    return jr.device_text ? FinishJobText(hs, jr) : FinishJobRows(j, hs);
+  }
+  static void FreeHandles(std::vector<bp_handle*>& hs) {
     for (bp_handle*& h : hs) {
       if (h) bp_destroy(h);
       h = nullptr;
     }
-    return err;
   }
 
   // One chunk of a job's rows on the host (with its per-read lists when those are asked for).
@@ -335,7 +355,6 @@ class Driver {
   std::string FinishJobText(std::vector<bp_handle*>& hs, const JobRows& jr) {
     for (size_t si = 0; si < streams.size(); si++) {
       bp_handle* h = hs[si];
-      if (bp_finish(h) != BP_OK) return HandleErr(h);
       for (int64_t first = jr.row_lo; first < jr.row_hi; first += kRowChunk) {
         const int64_t m = std::min<int64_t>(kRowChunk, jr.row_hi - first);
         // basestrand-tsv: one file; tsv: the .ref.tsv and the .alt.tsv lines of the same rows
@@ -360,8 +379,6 @@ class Driver {
     Chunk buf[2];
     for (size_t si = 0; si < streams.size(); si++) {
       bp_handle* h = hs[si];
-      if (bp_finish(h) != BP_OK) return HandleErr(h);
-      if (per_read && bp_per_read_build(h) != BP_OK) return HandleErr(h);
       const int64_t n = bp_num_rows(h);
       // the copy of chunk k+1 from the device runs while chunk k is rendered
       int cur = 0;
@@ -398,37 +415,41 @@ class Driver {
   int64_t bed_pad_ = 0;
 };
 
-// Jobs are closed (device computation, rows to the host, rendering, file writes) on a thread
-// of their own, in job order, while the main thread already reads the next job's records:
-// the reference overlaps its jobs across goroutines (pileup.go:862) and pays for the output
-// conversion serially at the end (output.go:143-148); here reading and output overlap instead.
-// At most one closed job waits behind the one being written, which bounds what stays resident
-// in HBM to three jobs.
+// Jobs are closed (device computation, rows to the host, rendering, file writes) on closer
+// threads, one per device, while the main thread already reads the next job's records: the
+// reference overlaps its jobs across goroutines (pileup.go:862) and pays for the output
+// conversion serially at the end (output.go:143-148); here reading, computing and output overlap.
+// A closer computes its job at once and then waits for its turn to write: output is in job order.
+// One job can wait behind the one a closer is working on, so a device holds three jobs at most
+// (the open one, one queued, one being closed).
+struct CloseGate {  // shared by the closers of a run
+  std::mutex mu;
+  std::condition_variable cv;
+  int64_t next_seq = 0;  // the job whose turn it is to write
+  std::string err;       // first error of the run, in job order as far as the turns go
+};
+
 class Closer {
  public:
-  explicit Closer(Driver* d) : drv_(d), th_([this] { Run(); }) {}
+  Closer(Driver* d, CloseGate* g) : drv_(d), gate_(g), th_([this] { Run(); }) {}
   ~Closer() { Join(); }
-  // Blocks while a job is already waiting.  Returns the first error seen so far.
+  // Blocks while a job is already waiting behind the one being closed.
   std::string Push(const Job& j, std::vector<bp_handle*> hs, const JobRows& jr) {
     std::unique_lock<std::mutex> lk(mu_);
-    cv_.wait(lk, [this] { return q_.empty() || !err_.empty(); });
-    if (!err_.empty()) {
-      for (bp_handle* h : hs) if (h) bp_destroy(h);
-      return err_;
-    }
+    cv_.wait(lk, [this] { return q_.size() < 2; });
     q_.push_back({j, std::move(hs), jr});
     cv_.notify_all();
-    return "";
+    lk.unlock();
+    std::unique_lock<std::mutex> gl(gate_->mu);
+    return gate_->err;
   }
-  // Waits for everything pushed; returns the first error.
-  std::string Join() {
+  void Join() {
     {
       std::unique_lock<std::mutex> lk(mu_);
       done_ = true;
       cv_.notify_all();
     }
     if (th_.joinable()) th_.join();
-    return err_;
   }
   double busy_s() const { return busy_s_; }
 
@@ -436,33 +457,45 @@ class Closer {
   struct Item { Job job; std::vector<bp_handle*> hs; JobRows rows; };
   void Run() {
     for (;;) {
-      Item it;
+      Item* it;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return !q_.empty() || done_; });
         if (q_.empty()) return;
-        it = std::move(q_.front());
+        it = &q_.front();  // stays in the queue while it is worked on: it counts against Push
       }
       const double t0 = Now();
       std::string e;
       {
-        std::unique_lock<std::mutex> lk(mu_);
-        e = err_;
+        std::unique_lock<std::mutex> gl(gate_->mu);
+        e = gate_->err;
       }
-      if (e.empty()) e = drv_->FinishJob(it.job, it.hs, it.rows);
-      else for (bp_handle* h : it.hs) if (h) bp_destroy(h);  // after an error: only free
+      if (e.empty()) e = drv_->ComputeJob(it->hs);
+      {
+        std::unique_lock<std::mutex> gl(gate_->mu);
+        gate_->cv.wait(gl, [&] { return gate_->next_seq == it->job.seq; });
+        if (gate_->err.empty()) gate_->err = e;
+        e = gate_->err;
+      }
+      if (e.empty()) e = drv_->OutputJob(it->job, it->hs, it->rows);
+      Driver::FreeHandles(it->hs);
+      {
+        std::unique_lock<std::mutex> gl(gate_->mu);
+        if (gate_->err.empty()) gate_->err = e;
+        gate_->next_seq++;
+        gate_->cv.notify_all();
+      }
       busy_s_ += Now() - t0;
       std::unique_lock<std::mutex> lk(mu_);
-      if (err_.empty()) err_ = e;
-      q_.pop_front();  // the slot frees only now: a waiting Push sees one job in flight
+      q_.pop_front();
       cv_.notify_all();
     }
   }
   Driver* drv_;
+  CloseGate* gate_;
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<Item> q_;
-  std::string err_;
   bool done_ = false;
   double busy_s_ = 0;
   std::thread th_;
@@ -567,9 +600,19 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     // the reference panics at the first pair it merges (pileup.go:422-443); refused up front
     return "stitched per-read features not yet supported";
   if (bp_init(opts.Device) != BP_OK) return bp_last_error(nullptr);
+  // -devices N | all: N logical devices, mapped round-robin onto the physical ones
+  std::vector<int> devices;
+  if (opts.Devices != 0) {
+    const int n_phys = bp_device_count();
+    if (n_phys <= 0) return bp_last_error(nullptr);
+    if (opts.Devices < -1 || opts.Devices > 1024) return "Pileup: invalid devices= argument";
+    const int n = opts.Devices == -1 ? n_phys : opts.Devices;
+    for (int k = 0; k < n; k++) devices.push_back(k % n_phys);
+  }
   SetHostThreads(opts.Parallelism);
 
   Driver drv(opts, hd, bed, tsv_format ? 1 : 0);
+  drv.devices = devices;
   drv.per_read = per_read;
   // without per-read columns the rows become text on the device (BIO_PILEUP_HOST_TEXT=1 keeps
   // the host renderer, for tests that compare the two)
@@ -601,7 +644,8 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (e.size() < 2) continue;
     for (int64_t s = (int64_t)e.front() / job_span * job_span; s < e.back(); s += job_span) {
       const int64_t t = std::min<int64_t>(s + job_span, kPosTypeMax);
-      if (bed.IntersectsByID((int)r, (PosType)s, (PosType)t)) jobs.push_back({(int)r, (PosType)s, (PosType)t});
+      if (bed.IntersectsByID((int)r, (PosType)s, (PosType)t))
+        jobs.push_back({(int)r, (PosType)s, (PosType)t, (int64_t)jobs.size()});
     }
   }
 
@@ -648,7 +692,9 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     return e;
   };
   const int64_t submit_records = SubmitRecords();
-  Closer closer(&drv);
+  CloseGate gate;
+  std::vector<std::unique_ptr<Closer>> closers;
+  for (size_t k = 0; k < drv.n_closers(); k++) closers.emplace_back(new Closer(&drv, &gate));
   // A full batch is packed and copied to the device (bp_submit) on a thread of its own while
   // the main thread goes on reading into the other builder; one batch in flight at most.
   RecordBatchBuilder inflight;
@@ -670,7 +716,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (e.empty()) e = drv.Submit(&pend[0]);
     st.submit_s += Now() - t0;
     t0 = Now();
-    if (e.empty()) e = closer.Push(jobs[ji], drv.TakeHandles(), drv.open_rows);
+    if (e.empty()) e = closers[ji % closers.size()]->Push(jobs[ji], drv.TakeHandles(), drv.open_rows);
     st.close_wait_s += Now() - t0;
     st.jobs++;
     open = false;
@@ -781,10 +827,10 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   }
   {
     const double t0 = Now();
-    const std::string e = closer.Join();
+    for (auto& c : closers) c->Join();
     st.close_wait_s += Now() - t0;
-    st.close_s = closer.busy_s();
-    if (err.empty()) err = e;
+    for (auto& c : closers) st.close_s += c->busy_s();
+    if (err.empty()) err = gate.err;
   }
   if (!err.empty()) {
     drv.Abort();

@@ -737,6 +737,15 @@ int bp_init(int32_t device) {
   return resolve_scratch(device);
 }
 
+int bp_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, BP_EDEVICE, "bp_device_count: no HIP device (%s); libbiopileup has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  return n;
+}
+
 int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const char* const* ref_name,
               bp_handle** out) {
   if (!opts || !out || n_ref < 0 || (n_ref > 0 && !ref_len)) return fail(nullptr, BP_EINVAL, "bp_create: null argument");

@@ -23,7 +23,7 @@ def _b(s):
     return None if s is None else s.encode()
 
 
-def pileup(xampath, fapath, fmt="tsv", out_prefix="bio-pileup", opts=None, device=0):
+def pileup(xampath, fapath, fmt="tsv", out_prefix="bio-pileup", opts=None, device=0, devices=0):
     """snp.Pileup (pileup.go:970).  Raises PileupError with the reference's wording."""
     o = opts or Opts()
     lib = _abi.load()
@@ -34,7 +34,7 @@ def pileup(xampath, fapath, fmt="tsv", out_prefix="bio-pileup", opts=None, devic
     co.max_read_len, co.max_read_span = o.MaxReadLen, o.MaxReadSpan
     co.min_bag_depth, co.min_base_qual, co.parallelism = o.MinBagDepth, o.MinBaseQual, o.Parallelism
     co.per_strand, co.remove_sq, co.stitch = int(o.PerStrand), int(o.RemoveSq), int(o.Stitch)
-    co.temp_dir, co.device = _b(o.TempDir), device
+    co.temp_dir, co.device, co.devices = _b(o.TempDir), device, devices
     e = _err()
     if lib.bio_pileup_run(_b(xampath), _b(fapath), _b(fmt), _b(out_prefix), C.byref(co), e, len(e)):
         raise PileupError(-1, e.value.decode())

@@ -114,6 +114,11 @@ typedef struct bp_timing {
  * CPU fallback in this library. */
 int bp_init(int32_t device);
 
+/* Number of HIP devices the library can run jobs on (bp_opts.device < this), or a negative BP_E*
+ * code.  For callers that spread their jobs over the GPUs of a node as the reference spreads them
+ * over goroutines (pileup.go:862-932). */
+int bp_device_count(void);
+
 /* newPileupMutable + pileupContext set-up for one job (pileup.go:189-209, :885-892).
  * ref_len[n_ref] = header reference lengths (sam.Header.Refs()). */
 int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len,

@@ -37,6 +37,10 @@ typedef struct bio_pileup_opts {
   int32_t stitch;
   const char* temp_dir;
   int32_t device; /* HIP device ordinal; no counterpart in the reference */
+  /* spread the jobs over this many logical devices, mapped round-robin onto the GPUs present
+   * (-1: one per GPU; 0: everything on `device`): the reference's -parallelism
+   * (pileup.go:862-932) with devices for goroutines */
+  int32_t devices;
 } bio_pileup_opts;
 
 /* snp.DefaultOpts (pileup.go:56-68) */

@@ -284,6 +284,35 @@ def test_job_cuts_with_halo_change_nothing(tmp_path, stitch, monkeypatch):
         assert c.read("sub.basestrand.tsv") == want, span
 
 
+@pytest.mark.parametrize("fmt_cols", [("basestrand-tsv", ""), ("tsv", "dpref,quals,strands")])
+def test_jobs_spread_over_devices_change_nothing(tmp_path, monkeypatch, fmt_cols):
+    """-devices N: job k runs on logical device k mod N (mapped round-robin onto the GPUs present:
+    on a one-GPU box all of them land on that GPU, each with its own closer thread), jobs are
+    computed concurrently and written in job order.  The files are those of a run on one device,
+    byte for byte - device-rendered text and host-rendered per-read columns alike - and the
+    command line takes the flag."""
+    import subprocess
+    fmt, cols = fmt_cols
+    c = Case(tmp_path, seed=21)
+    o = Opts(BedPath=c.bed_path, Cols=cols, MinBaseQual=13)
+    monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", "900")
+    names = ["basestrand.tsv"] if fmt == "basestrand-tsv" else ["ref.tsv", "alt.tsv"]
+    host.pileup(c.bam, c.fa, fmt, str(tmp_path / "one"), o)
+    want = [c.read("one." + n) for n in names]
+    assert all(w.count("\n") > 100 for w in want[:1])
+    for devices in (1, 3, 5, -1):
+        host.pileup(c.bam, c.fa, fmt, str(tmp_path / "many"), o, devices=devices)
+        assert [c.read("many." + n) for n in names] == want, devices
+    exe = os.path.join(os.path.dirname(host.__file__), "bio-pileup")
+    args = [exe, "-bed", c.bed_path, "-format", fmt, "-min-base-qual", "13", "-devices", "4", "-out", str(tmp_path / "cli")]
+    if cols:
+        args += ["-cols", cols]
+    subprocess.run(args + [c.bam, c.fa], check=True, timeout=120)
+    assert [c.read("cli." + n) for n in names] == want
+    r = subprocess.run([exe, "-bed", c.bed_path, "-devices", "0", c.bam, c.fa], capture_output=True, timeout=60)
+    assert r.returncode == 2 and b"-devices" in r.stderr
+
+
 def test_per_strand(tmp_path):
     c = Case(tmp_path, seed=15)
     out = str(tmp_path / "ps")

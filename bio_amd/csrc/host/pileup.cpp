@@ -760,16 +760,24 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (region_ref >= 0) {  // iterator of the single region shard (bamprovider.go:417-435)
       if (r.ref_id < region_ref || (r.ref_id == region_ref && r.pos < region.start0)) continue;
       if (r.ref_id > region_ref || r.pos >= region.end) break;
-    } else if (index.loaded()) {
+    } else {
+      // The reference scans whole 100 kb position shards and only those that meet the padded BED
+      // (bamprovider.go:262-263, pileup_support.go:71-85): a record is scanned - and goes through
+      // the read-length checks - iff its shard does.  The same rule here, index or not: both
+      // ways the device is fed the same records and raises the same errors; the index only saves
+      // reading the rest.
       if (r.ref_id < skip_ref || (r.ref_id == skip_ref && r.pos < skip_pos)) continue;
+      const int64_t shard0 = (int64_t)r.pos / kSeekGap * kSeekGap;
       int nref = 0;
       int64_t nstart = 0;
-      if (!need.Next(r.ref_id, r.pos, &nref, &nstart)) break;  // past the last BED interval
-      if (nref != r.ref_id || nstart - r.pos > kSeekGap) {
+      if (!need.Next(r.ref_id, shard0, &nref, &nstart)) break;  // past the last BED interval
+      if (nref != r.ref_id || nstart >= shard0 + kSeekGap) {
+        if (!index.loaded()) continue;
+        const int64_t target = nstart / kSeekGap * kSeekGap;  // the first record of the next shard that is scanned
         uint64_t voff = 0;
-        if (!index.Offset(nref, (int32_t)nstart, &voff)) break;  // no records from there on
+        if (!index.Offset(nref, (int32_t)target, &voff)) break;  // no records from there on
         skip_ref = nref;
-        skip_pos = nstart;
+        skip_pos = target;
         if ((voff >> 16) > bam.BlockOffset()) {
           flush_raw();
           if (!(err = bam.Seek(voff)).empty()) break;

@@ -364,7 +364,7 @@ def test_index_seeks_change_nothing(tmp_path):
     recs.sort(key=lambda x: (x["ref_id"], x["pos"]))
     batch = R.from_records(recs)
     ascii_ = ["".join(rng.choice("ACGT") for _ in range(l)) for l in ref_lens]
-    bed = {0: [[1000, 1500], [300_000, 300_400], [650_000, 650_100]], 1: [[10, 20]], 2: [[200_000, 200_300]]}
+    bed = {0: [[1000, 1500], [350_000, 350_400], [640_000, 640_100]], 1: [[10, 20]], 2: [[250_000, 250_300]]}
     fa, bedp = str(tmp_path / "r.fa"), str(tmp_path / "t.bed")
     bamio.write_fasta(fa, ref_names, ascii_)
     bamio.write_bed(bedp, [(r, s, e) for r in sorted(bed) for s, e in bed[r]], ref_names)
@@ -381,24 +381,46 @@ def test_index_seeks_change_nothing(tmp_path):
         return open(str(tmp_path / tag) + ".basestrand.tsv").read(), [int(x) for x in m.groups()]
 
     want = render_basestrand(O.pileup(O.make_opts(mapq=0), ref_lens, bed, batch), ref_names, ascii_)
-    got, (n_read, _, seeks) = run(plain, "p", "-bed", bedp)
-    assert got == want and seeks == 0 and n_read == batch.n
-    shard, n = O.region_shard(2, 199_000, 201_000)
-    want_region = render_basestrand(O.pileup(O.make_opts(mapq=0), ref_lens, {2: [[199_000, 201_000]]}, batch,
+    got, (n_read, kept_plain, seeks) = run(plain, "p", "-bed", bedp)
+    assert got == want and seeks == 0 and batch.n // 2 < n_read <= batch.n  # (it stops behind the last interval)
+    shard, n = O.region_shard(2, 249_000, 251_000)
+    want_region = render_basestrand(O.pileup(O.make_opts(mapq=0), ref_lens, {2: [[249_000, 251_000]]}, batch,
                                              shards=shard, n_shards=n), ref_names, ascii_)
     for kind in ("bai", "gbai"):
         bam = str(tmp_path / f"{kind}.bam")
         bamio.write_bam(bam, ref_names, ref_lens, batch, index=kind)
-        got, (n_read, _, seeks) = run(bam, kind, "-bed", bedp)
+        got, (n_read, kept, seeks) = run(bam, kind, "-bed", bedp)
         assert got == want, kind
-        assert seeks >= 4 and n_read < batch.n // 4, (kind, seeks, n_read)
-        got, (n_read, _, seeks) = run(bam, kind + "r", "-region", "chr3:199001-201000")
+        assert seeks >= 3 and n_read < batch.n // 2, (kind, seeks, n_read)
+        # index or not, the device is fed the same records: those of the 100 kb position shards
+        # that meet the padded BED (what the reference scans)
+        assert kept == kept_plain < batch.n // 2, (kind, kept, kept_plain)
+        got, (n_read, _, seeks) = run(bam, kind + "r", "-region", "chr3:249001-251000")
         assert got == want_region and seeks == 1 and n_read < batch.n // 8, (kind, seeks, n_read)
         # -index names the file explicitly
         moved = str(tmp_path / f"elsewhere.{kind}")
         shutil.move(bam + "." + kind, moved)
         got, (n_read, _, seeks) = run(bam, kind + "x", "-bed", bedp, "-index", moved)
-        assert got == want and seeks >= 4
+        assert got == want and seeks >= 3
+    # ... so an over-long read far from every interval is an error neither way, and one near an
+    # interval is an error both ways (pileup.go:766-768 is checked before the BED test)
+    def with_long_read(pos):
+        x = dict(recs[0], name="toolong", ref_id=0, mate_ref_id=0, pos=pos, mate_pos=pos, cigar=[("M", 600)],
+                 seq="A" * 600, qual=[30] * 600, mapq=60, flags=0x63)
+        rr = sorted(recs + [x], key=lambda y: (y["ref_id"], y["pos"]))
+        return R.from_records(rr)
+    for pos, fails in ((450_000, False), (349_000, True)):
+        b2 = with_long_read(pos)
+        for kind in (None, "bai"):
+            bam = str(tmp_path / f"long{pos}{kind}.bam")
+            bamio.write_bam(bam, ref_names, ref_lens, b2, index=kind)
+            r = subprocess.run([exe, "-bed", bedp, "-format", "basestrand-tsv", "-mapq", "0", "-out", str(tmp_path / "lg"), bam, fa],
+                               capture_output=True, text=True, timeout=300)
+            if fails:
+                assert r.returncode != 0 and "maxReadLen is 500, but read toolong" in r.stderr, (pos, kind, r.stderr)
+            else:
+                assert r.returncode == 0, (pos, kind, r.stderr)
+                assert open(str(tmp_path / "lg") + ".basestrand.tsv").read() == want
     r = subprocess.run([exe, "-bed", bedp, "-index", str(tmp_path / "nope.bai"), "-out", str(tmp_path / "z"), plain, fa],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no such file" in r.stderr

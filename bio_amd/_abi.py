@@ -65,7 +65,7 @@ class bp_timing(C.Structure):
 
 
 EXPORTS = [
-    "bp_init", "bp_device_count", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_finish", "bp_compute", "bp_compute_static",
+    "bp_init", "bp_device_count", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_submit_bam", "bp_finish", "bp_compute", "bp_compute_static",
     "bp_num_rows", "bp_rows", "bp_rows_device", "bp_rows_export", "bp_rows_accumulate", "bp_rows_export_async", "bp_rows_accumulate_async", "bp_stream", "bp_column_sums", "bp_get_timing",
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
@@ -131,6 +131,8 @@ def load():
     lib.bp_set_bed.restype = C.c_int
     lib.bp_submit.argtypes = [H, C.POINTER(bp_record_batch)]
     lib.bp_submit.restype = C.c_int
+    lib.bp_submit_bam.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_int64]
+    lib.bp_submit_bam.restype = C.c_int
     lib.bp_finish.argtypes = [H]
     lib.bp_finish.restype = C.c_int
     lib.bp_compute.argtypes = [H]

@@ -174,3 +174,69 @@ def write_bed(path, intervals, ref_names, gz=False):
     with op(path, "wb") as f:
         for r, s, e in intervals:
             f.write(f"{ref_names[r]}\t{s}\t{e}\ttarget\n".encode())
+
+
+def record_stream(batch, aux_bytes=0):
+    """The records of `batch` as they lie in an inflated BAM stream (SAM spec 4.2), for
+    bp_submit_bam: (uint8 array, uint32 offsets of each record's block_size field).  Names are
+    the batch's (else r<i>); aux_bytes > 0 appends that many bytes of one `XX:Z:` tag to every
+    record so that the fields do not end where the record does."""
+    b = batch
+    n = int(b.n)
+    have_names = b.name_off is not None and b.name is not None
+    if have_names:
+        noff = np.asarray(b.name_off, np.int64)
+        nlen = noff[1:n + 1] - noff[:n]
+        names = np.asarray(b.name, np.uint8)
+    else:
+        parts = [b"r%d" % i for i in range(n)]
+        nlen = np.array([len(x) for x in parts], np.int64)
+        noff = np.concatenate([[0], np.cumsum(nlen)])
+        names = np.frombuffer(b"".join(parts), np.uint8)
+    if n and nlen.max() > 254:
+        raise ValueError("read name longer than 254 bytes")
+    nc = np.asarray(b.n_cigar, np.int64)[:n]
+    ls = np.asarray(b.l_seq, np.int64)[:n]
+    sb = (ls + 1) // 2
+    if aux_bytes and aux_bytes < 4:
+        raise ValueError("aux_bytes: 0 or at least 4 (tag, type, NUL)")
+    body = 32 + nlen + 1 + 4 * nc + sb + ls + aux_bytes
+    off = np.concatenate([[0], np.cumsum(4 + body)])
+    out = np.zeros(int(off[-1]), np.uint8)
+    fixed = np.zeros(n, dtype=np.dtype([("bs", "<u4"), ("ref", "<i4"), ("pos", "<i4"), ("ln", "u1"), ("mapq", "u1"),
+                                        ("bin", "<u2"), ("nc", "<u2"), ("flag", "<u2"), ("ls", "<u4"),
+                                        ("mref", "<i4"), ("mpos", "<i4"), ("tlen", "<i4")]))
+    fixed["bs"] = body
+    fixed["ref"] = np.asarray(b.ref_id)[:n]
+    fixed["pos"] = np.asarray(b.pos)[:n]
+    fixed["ln"] = nlen + 1
+    fixed["mapq"] = np.asarray(b.mapq)[:n]
+    fixed["bin"] = 4680
+    fixed["nc"] = nc
+    fixed["flag"] = np.asarray(b.flags)[:n]
+    fixed["ls"] = ls
+    fixed["mref"] = np.asarray(b.mate_ref_id)[:n]
+    fixed["mpos"] = np.asarray(b.mate_pos)[:n]
+    out[(off[:n, None] + np.arange(36)[None, :]).reshape(-1)] = fixed.view(np.uint8).reshape(-1)
+
+    def scatter(dst0, src, src0, lens):
+        lens = np.asarray(lens, np.int64)
+        tot = int(lens.sum())
+        if tot == 0:
+            return
+        first = np.cumsum(lens) - lens
+        ar = np.arange(tot)
+        out[np.repeat(dst0 - first, lens) + ar] = src[np.repeat(np.asarray(src0, np.int64) - first, lens) + ar]
+    at = off[:n] + 36
+    scatter(at, names, noff[:n], nlen)
+    at = at + nlen + 1
+    scatter(at, np.asarray(b.cigar, np.uint32).view(np.uint8), 4 * np.asarray(b.cigar_off, np.int64)[:n], 4 * nc)
+    at = at + 4 * nc
+    scatter(at, np.asarray(b.seq, np.uint8), np.asarray(b.seq_off, np.int64)[:n], sb)
+    at = at + sb
+    scatter(at, np.asarray(b.qual, np.uint8), np.asarray(b.qual_off, np.int64)[:n], ls)
+    at = at + ls
+    if aux_bytes:
+        tag = np.frombuffer(b"XXZ" + b"a" * (aux_bytes - 4) + b"\0", np.uint8)
+        out[(at[:, None] + np.arange(aux_bytes)[None, :]).reshape(-1)] = np.tile(tag, n)
+    return out, off[:n].astype(np.uint32)

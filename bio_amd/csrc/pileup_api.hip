@@ -25,6 +25,8 @@
 #include <vector>
 
 #include "../../include/bio_pileup.h"
+#include "pack_device.h"
+#include "par.h"
 #include "pileup_device.h"
 
 namespace bp {
@@ -38,6 +40,8 @@ void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned
 void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s);
 void launch_text(const TextParams& T, hipStream_t s);
 void launch_text_write(const TextParams& T, hipStream_t s);
+void launch_pack(const uint8_t* raw, const PackItem* items, int64_t n, ReadCore* cores, uint8_t* blob,
+                 hipStream_t s);
 }  // namespace bp
 
 using namespace bp;
@@ -75,9 +79,12 @@ struct DevBuf {
   }
 };
 
-struct Staging {
-  ReadCore* cores = nullptr;
+struct Staging {  // pinned host memory of one slice in flight; each part allocated when first used
+  ReadCore* cores = nullptr;  // bp_submit: packed on the host
   uint8_t* blob = nullptr;
+  PackItem* items = nullptr;  // bp_submit_bam: packed on the device
+  uint8_t* raw = nullptr;     // ... record bytes gathered here when they cannot go straight from the caller's memory
+  size_t raw_cap = 0;
   hipEvent_t done = nullptr;
   bool busy = false;
 };
@@ -262,6 +269,11 @@ struct bp_handle {
   bool mate_dirty = true;                             // changed since it was last copied to the device
   FirstReadTable stored;
   std::vector<uint8_t> scan_cls;
+  // bp_submit_bam: fixed fields of the call's records, pulled out of the stream
+  std::vector<int32_t> x_ref, x_pos, x_mref, x_mpos;
+  std::vector<uint16_t> x_flags;
+  std::vector<uint8_t> x_mapq, x_lname;
+  std::vector<uint32_t> x_ncig, x_lseq, x_bytes;
   std::vector<uint64_t> scan_hash;
   double scan_s = 0, pack_s = 0;                      // host time in bp_submit so far: serial scan (order, errors, pairing) / parallel passes
   uint8_t qthr[96];
@@ -270,7 +282,7 @@ struct bp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
-      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_tile_lo, d_pr_feat, d_seq8, d_refname, d_txt_len, d_txt_tile, d_txt_out, d_items, d_coarse;
+      d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_tile_lo, d_pr_feat, d_seq8, d_refname, d_txt_len, d_txt_tile, d_txt_out, d_items, d_coarse, d_raw, d_pack;
   bool per_read_valid = false;
   int32_t seq_ref = -1, seq_start = 0;  // bp_set_ref_seq8
   int64_t seq_len = 0;
@@ -467,24 +479,7 @@ int freeze_bed(bp_handle* h) {
   return 0;
 }
 
-template <class F>
-void parallel_for(size_t n, int threads, F f) {
-  if (threads <= 1 || n < 2) {
-    for (size_t i = 0; i < n; i++) f(i);
-    return;
-  }
-  std::atomic<size_t> next(0);
-  std::vector<std::thread> ts;
-  for (int t = 0; t < threads; t++)
-    ts.emplace_back([&] {
-      for (;;) {
-        size_t i = next.fetch_add(1);
-        if (i >= n) break;
-        f(i);
-      }
-    });
-  for (auto& t : ts) t.join();
-}
+using bp_par::parallel_for;
 
 int pack_threads() {
   unsigned hc = std::thread::hardware_concurrency();
@@ -492,23 +487,53 @@ int pack_threads() {
   return std::max(t, 1);
 }
 
-inline int32_t cigar_span(const uint32_t* c, uint32_t n, bool* simple, bool* has_bad) {
+inline uint32_t cigar_op_at(const uint8_t* c, uint32_t k) {  // (a BAM stream gives CIGARs no alignment)
+  uint32_t v;
+  memcpy(&v, c + 4 * (size_t)k, 4);
+  return v;
+}
+
+inline int32_t cigar_span(const uint8_t* c, uint32_t n, bool* simple, bool* has_bad) {
   int64_t span = 0;
   bool bad = false;
   for (uint32_t k = 0; k < n; k++) {
-    uint32_t op = c[k] & 15u, len = c[k] >> 4;
+    const uint32_t v = cigar_op_at(c, k), op = v & 15u, len = v >> 4;
     // sam.Cigar.Lengths(): M, D, N, =, X consume the reference
     if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += len;
     if (op > 5) bad = true;
   }
-  *simple = (n == 1 && (c[0] & 15u) == 0);
+  *simple = (n == 1 && (cigar_op_at(c, 0) & 15u) == 0);
   *has_bad = bad;
   return span > 0x7fffffff ? 0x7fffffff : (int32_t)span;
 }
 
-std::string read_name(const bp_record_batch* b, int64_t i) {
-  if (!b->name || !b->name_off) return std::string();
-  return std::string((const char*)b->name + b->name_off[i], (size_t)(b->name_off[i + 1] - b->name_off[i]));
+// The records of one submit call: decoded columns (bp_submit), or the records as they lie in an
+// inflated BAM stream (bp_submit_bam) with their fixed fields pulled out into columns first.
+struct Src {
+  int64_t n = 0;
+  const int32_t *ref_id = nullptr, *pos = nullptr, *mate_ref_id = nullptr, *mate_pos = nullptr;
+  const uint16_t* flags = nullptr;
+  const uint8_t* mapq = nullptr;
+  const uint32_t *n_cigar = nullptr, *l_seq = nullptr;
+  const bp_record_batch* b = nullptr;  // column mode: where the payloads are
+  const uint8_t* raw = nullptr;        // stream mode: record i starts (block_size field) at raw + off[i]
+  const uint32_t* off = nullptr;
+  const uint8_t* l_name = nullptr;     // stream mode: l_read_name (with the NUL)
+  const uint32_t* rec_bytes = nullptr; // stream mode: 4 + block_size
+
+  const uint8_t* cigar(int64_t i) const {
+    return raw ? raw + off[i] + 36 + l_name[i] : (const uint8_t*)(b->cigar + b->cigar_off[i]);
+  }
+  bool has_names() const { return raw || (b->name && b->name_off); }
+  const uint8_t* name(int64_t i) const { return raw ? raw + off[i] + 36 : b->name + b->name_off[i]; }
+  uint32_t name_len(int64_t i) const {
+    return raw ? (l_name[i] ? l_name[i] - 1u : 0u) : (uint32_t)(b->name_off[i + 1] - b->name_off[i]);
+  }
+};
+
+std::string read_name(const Src& S, int64_t i) {
+  if (!S.has_names()) return std::string();
+  return std::string((const char*)S.name(i), (size_t)S.name_len(i));
 }
 
 const char* ref_label(bp_handle* h, int32_t ref, char* tmp, size_t n) {
@@ -534,7 +559,7 @@ enum : uint8_t {
 // the data errors (the first one in record order is the one reported, as the reference would
 // meet it) and the firstread table.  boff/qoff/blob_base: where the packer will put each record's
 // payload (a paired read's mate entry names it).
-int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, std::vector<int32_t>& spans,
+int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<int32_t>& spans,
                std::vector<uint8_t>& simple, const std::vector<uint64_t>& boff, const std::vector<uint64_t>& qoff,
                uint32_t blob_base, int nthreads) {
   const bp_opts& o = h->o;
@@ -549,27 +574,27 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, s
   parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
     for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
       const int64_t i = i0 + (int64_t)k;
-      const uint32_t n_cigar = b->n_cigar[i];
+      const uint32_t n_cigar = S.n_cigar[i];
       if (n_cigar > 0xffffu) {
         cls[k] = SC_MANY_OPS;
         continue;
       }
       bool simp = false, has_bad = false;
-      const int32_t span = cigar_span(b->cigar + b->cigar_off[i], n_cigar, &simp, &has_bad);
+      const int32_t span = cigar_span(S.cigar(i), n_cigar, &simp, &has_bad);
       spans[k] = span;
       simple[k] = simp ? 1 : 0;
-      const int32_t ref = b->ref_id[i], pos = b->pos[i];
-      const uint32_t flags = b->flags[i];
-      if (((uint32_t)o.flag_exclude & flags) != 0 || o.mapq > (int32_t)b->mapq[i] || n_cigar == 0) continue;
+      const int32_t ref = S.ref_id[i], pos = S.pos[i];
+      const uint32_t flags = S.flags[i];
+      if (((uint32_t)o.flag_exclude & flags) != 0 || o.mapq > (int32_t)S.mapq[i] || n_cigar == 0) continue;
       if (ref < 0 || ref >= nref) continue;  // unmapped: never in a shard
-      const int strand = strand_of(ref, b->mate_ref_id[i], flags);
+      const int strand = strand_of(ref, S.mate_ref_id[i], flags);
       if (o.strand_req != BP_STRAND_NONE) {
         if (strand != o.strand_req) continue;
       } else if (strand == 0 && !o.ignore_strand) {
         continue;
       }
       uint8_t f = SC_KEPT;
-      if ((int64_t)b->l_seq[i] > (int64_t)o.max_read_len || span > o.max_read_span) {
+      if ((int64_t)S.l_seq[i] > (int64_t)o.max_read_len || span > o.max_read_span) {
         cls[k] = f | SC_TOO_LONG;
         continue;
       }
@@ -579,10 +604,10 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, s
         if (has_bad) f |= SC_BAD_OP;
         if (o.stitch) {
           // firstreadSNPTable.addOrRemove (firstread.go:180): processed alone right away?
-          const int32_t mate_pos = b->mate_pos[i];
+          const int32_t mate_pos = S.mate_pos[i];
           if (!(strand == 0 || mate_pos >= map_end || (int64_t)mate_pos + o.max_read_span <= (int64_t)pos)) {
             f |= SC_PAIRABLE;
-            hashes[k] = name_hash(b->name + b->name_off[i], (size_t)(b->name_off[i + 1] - b->name_off[i]));
+            hashes[k] = name_hash(S.name(i), (size_t)S.name_len(i));
           }
         }
       }
@@ -600,7 +625,7 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, s
   for (size_t k = 0; k < ns; k++) {
     const int64_t i = i0 + (int64_t)k;
     const int64_t gidx = h->n_reads + (int64_t)k;
-    const int32_t ref = b->ref_id[i], pos = b->pos[i];
+    const int32_t ref = S.ref_id[i], pos = S.pos[i];
     const uint64_t key = sort_key(ref, pos);
     if (key < h->last_key)
       return fail(h, BP_EUNSORTED, "bp_submit: record %lld (ref %d pos %d) is out of coordinate order",
@@ -615,49 +640,46 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, s
     const uint8_t f = cls[k];
     if (!f) continue;
     if (f & SC_MANY_OPS)
-      return fail(h, BP_EINVAL, "bp_submit: record with %u CIGAR ops (limit 65535)", b->n_cigar[i]);
+      return fail(h, BP_EINVAL, "bp_submit: record with %u CIGAR ops (limit 65535)", S.n_cigar[i]);
     const int32_t span = spans[k];
     char tmp[32];
     if (f & SC_TOO_LONG) {
       // ring-buffer sizing assumptions (pileup.go:766-772), checked before the BED test
-      if ((int64_t)b->l_seq[i] > (int64_t)o.max_read_len)
+      if ((int64_t)S.l_seq[i] > (int64_t)o.max_read_len)
         return fail(h, BP_EDATA,
                     "pileupMutable.processShard: maxReadLen is %d, but read %s at %s:%d has length %u",
-                    o.max_read_len, read_name(b, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
-                    b->l_seq[i]);
+                    o.max_read_len, read_name(S, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
+                    S.l_seq[i]);
       return fail(h, BP_EDATA,
                   "pileupMutable.processShard: maxReadSpan is %d, but read %s at %s:%d has span %d",
-                  o.max_read_span, read_name(b, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
+                  o.max_read_span, read_name(S, i).c_str(), ref_label(h, ref, tmp, sizeof tmp), pos,
                   span);
     }
     if (span > h->max_span) h->max_span = span;
     if (f & SC_BAD_OP) {
       // alignRelevantBases (pileup.go:355-359) fails at the first op outside MIDNSH that its
       // walk reaches, i.e. one starting before the end of the last overlapping interval.
-      const uint32_t* cg = b->cigar + b->cigar_off[i];
+      const uint8_t* cg = S.cigar(i);
       const int32_t last_end = bed_last_overlap_end(h->bed[(size_t)ref], pos + span);
       int32_t rp = pos;
-      for (uint32_t c = 0; c < b->n_cigar[i]; c++) {
-        uint32_t op = cg[c] & 15u, len = cg[c] >> 4;
+      for (uint32_t c = 0; c < S.n_cigar[i]; c++) {
+        const uint32_t v = cigar_op_at(cg, c), op = v & 15u, len = v >> 4;
         if (rp >= last_end) break;
         if (op == 0 || op == 2 || op == 3) rp += (int32_t)len;
         else if (op > 5)
           return fail(h, BP_EDATA, "alignRelevantBases: unexpected CIGAR code %u%c (read %s at %s:%d)",
-                      len, "MIDNSHP=XB??????"[op], read_name(b, i).c_str(),
+                      len, "MIDNSHP=XB??????"[op], read_name(S, i).c_str(),
                       ref_label(h, ref, tmp, sizeof tmp), pos);
       }
     }
     if (!(f & SC_PAIRABLE)) continue;
-#ifdef BP_EXP_NOPAIR
-    continue;
-#endif
     // firstreadSNPTable.addOrRemove (firstread.go:176-204)
     FirstReadTable& T = h->stored;
     T.advance(ref, pos);
-    const int32_t mate_pos = b->mate_pos[i];
-    const uint8_t* nm = b->name + b->name_off[i];
-    const uint32_t nlen = (uint32_t)(b->name_off[i + 1] - b->name_off[i]);
-    const int strand = strand_of(ref, b->mate_ref_id[i], b->flags[i]);
+    const int32_t mate_pos = S.mate_pos[i];
+    const uint8_t* nm = S.name(i);
+    const uint32_t nlen = S.name_len(i);
+    const int strand = strand_of(ref, S.mate_ref_id[i], S.flags[i]);
     StoredRead me{};
     me.hash = hashes[k];
     me.key_pos = mate_pos;
@@ -666,8 +688,8 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, s
     me.name_len = nlen;
     me.self.x = (simple[k] ? MATE_SIMPLE : 0u) | MATE_HAS;
     me.self.blob = blob_base + (uint32_t)(boff[k] / 8);
-    me.self.span_lseq = (uint32_t)span | ((uint32_t)b->l_seq[i] << 16);
-    me.self.ncig_qdelta = b->n_cigar[i] | ((uint32_t)((qoff[k] - boff[k]) / 8) << 16);
+    me.self.span_lseq = (uint32_t)span | ((uint32_t)S.l_seq[i] << 16);
+    me.self.ncig_qdelta = S.n_cigar[i] | ((uint32_t)((qoff[k] - boff[k]) / 8) << 16);
     if (pos >= mate_pos) {
       StoredRead a;
       if (T.try_remove(pos, mate_pos, me.hash, nm, nlen, &a)) {
@@ -687,20 +709,41 @@ int scan_slice(bp_handle* h, const bp_record_batch* b, int64_t i0, int64_t i1, s
   return 0;
 }
 
-int acquire_stage(bp_handle* h, Staging** out) {
+int acquire_stage(bp_handle* h, Staging** out, bool stream_mode, size_t raw_bytes) {
   Staging& s = h->stage[h->cur_stage];
   h->cur_stage ^= 1;
-  if (!s.cores) {
-    HIP_TRY(h, hipHostMalloc((void**)&s.cores, kStageReads * sizeof(ReadCore), hipHostMallocDefault));
-    HIP_TRY(h, hipHostMalloc((void**)&s.blob, kStageBlob, hipHostMallocDefault));
-    HIP_TRY(h, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-  }
+  if (!s.done) HIP_TRY(h, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   if (s.busy) {
     HIP_TRY(h, hipEventSynchronize(s.done));
     s.busy = false;
   }
+  if (!stream_mode && !s.cores) {
+    HIP_TRY(h, hipHostMalloc((void**)&s.cores, kStageReads * sizeof(ReadCore), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc((void**)&s.blob, kStageBlob, hipHostMallocDefault));
+  }
+  if (stream_mode && !s.items)
+    HIP_TRY(h, hipHostMalloc((void**)&s.items, kStageReads * sizeof(PackItem), hipHostMallocDefault));
+  if (raw_bytes > s.raw_cap) {
+    if (s.raw) (void)hipHostFree(s.raw);
+    s.raw = nullptr;
+    s.raw_cap = 0;
+    const size_t cap = std::max<size_t>(raw_bytes + raw_bytes / 4, 32u << 20);
+    HIP_TRY(h, hipHostMalloc((void**)&s.raw, cap, hipHostMallocDefault));
+    s.raw_cap = cap;
+  }
   *out = &s;
   return 0;
+}
+
+// Is p memory the device can copy from by itself (hipHostMalloc / hipHostRegister)?
+bool host_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
 }
 
 constexpr int kMaxDevices = 64;
@@ -813,12 +856,13 @@ int bp_set_bed(bp_handle* h, int32_t ref_id, const int32_t* endpoints, int32_t n
   return BP_OK;
 }
 
-int bp_submit(bp_handle* h, const bp_record_batch* b) {
-  if (!h || !b) return fail(h, BP_EINVAL, "bp_submit: null argument");
-  if (h->finished) return fail(h, BP_EINVAL, "bp_submit: called after bp_finish");
-  if (b->n < 0) return fail(h, BP_EINVAL, "bp_submit: negative record count");
-  if (h->o.stitch && b->n > 0 && (!b->name || !b->name_off))
-    return fail(h, BP_EINVAL, "bp_submit: stitch mode needs read names (firstread.go:135-152)");
+// One submit call, either kind.  (Runs between `extern "C" {` and its end: plain C++ linkage is
+// all it needs, it is static.)
+static int submit_records(bp_handle* h, const Src& S, const char* who) {
+  if (h->finished) return fail(h, BP_EINVAL, "%s: called after bp_finish", who);
+  if (S.n < 0) return fail(h, BP_EINVAL, "%s: negative record count", who);
+  if (h->o.stitch && S.n > 0 && !S.has_names())
+    return fail(h, BP_EINVAL, "%s: stitch mode needs read names (firstread.go:135-152)", who);
   if (h->poison_code) return fail(h, h->poison_code, "%s", h->poison_msg.c_str());
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = freeze_bed(h)) return rc;
@@ -834,122 +878,265 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
     }
   } poison{h};
   const int nthreads = pack_threads();
+  const bool stream_mode = S.raw != nullptr;
+  const bool pinned_src = stream_mode && S.n > 0 && host_pinned(S.raw + S.off[0]);
+  bool wait_for_copy = false;  // a copy out of the caller's own memory is in flight
   std::vector<int32_t> spans;
   std::vector<uint8_t> simple;
   std::vector<uint64_t> boff, qoff;
+  std::vector<uint32_t> gsrc;
   // a record longer than the core can say (0xffff) passes no max-read-len: no payload kept
   auto plen = [](uint32_t l) { return l > 0xffffu ? 0u : l; };
   int64_t i0 = 0;
-  while (i0 < b->n) {
+  while (i0 < S.n) {
     // slice bounded by staging capacity
     int64_t i1 = i0;
     uint64_t bytes = 0;
     boff.clear();
     qoff.clear();
-    while (i1 < b->n && (size_t)(i1 - i0) < kStageReads) {
+    while (i1 < S.n && (size_t)(i1 - i0) < kStageReads) {
       // one group: base parts back to back, then the qual parts
       int64_t g1 = i1;
       uint64_t ga = 0, gq = 0;
-      while (g1 < b->n && g1 - i1 < kGroupRecs && (size_t)(g1 - i0) < kStageReads) {
-        const uint64_t a = base_part_bytes(b->n_cigar[g1], plen(b->l_seq[g1])), q = qual_part_bytes(plen(b->l_seq[g1]));
-        if (a + q > kGroupBytes) return fail(h, BP_EINVAL, "bp_submit: record payload of %llu bytes", (unsigned long long)(a + q));
+      while (g1 < S.n && g1 - i1 < kGroupRecs && (size_t)(g1 - i0) < kStageReads) {
+        const uint64_t a = base_part_bytes(S.n_cigar[g1], plen(S.l_seq[g1])), q = qual_part_bytes(plen(S.l_seq[g1]));
+        if (a + q > kGroupBytes) return fail(h, BP_EINVAL, "%s: record payload of %llu bytes", who, (unsigned long long)(a + q));
         if (ga + gq + a + q > kGroupBytes) break;
         ga += a;
         gq += q;
         g1++;
       }
       if (bytes + ga + gq > kStageBlob) break;
+      // the stream bytes of a slice travel in one piece too
+      if (stream_mode && g1 > i0 && (uint64_t)S.off[g1 - 1] + S.rec_bytes[g1 - 1] - S.off[i0] > kStageBlob && i1 > i0) break;
       uint64_t ao = bytes, qo = bytes + ga;
       for (int64_t i = i1; i < g1; i++) {
         boff.push_back(ao);
         qoff.push_back(qo);
-        ao += base_part_bytes(b->n_cigar[i], plen(b->l_seq[i]));
-        qo += qual_part_bytes(plen(b->l_seq[i]));
+        ao += base_part_bytes(S.n_cigar[i], plen(S.l_seq[i]));
+        qo += qual_part_bytes(plen(S.l_seq[i]));
       }
       bytes += ga + gq;
       i1 = g1;
     }
     const size_t ns = (size_t)(i1 - i0);
     if ((uint64_t)h->blob_used + bytes / 8 > 0xffffffffull)
-      return fail(h, BP_ENOMEM, "bp_submit: more than 32 GiB of record payload in one job");
+      return fail(h, BP_ENOMEM, "%s: more than 32 GiB of record payload in one job", who);
     if (h->n_reads + (int64_t)ns > 0x7fffffff)
-      return fail(h, BP_ENOMEM, "bp_submit: more than 2^31-1 records in one job");
+      return fail(h, BP_ENOMEM, "%s: more than 2^31-1 records in one job", who);
     spans.assign(ns, 0);
     simple.assign(ns, 0);
     if (h->o.stitch) {
       h->mate.resize((size_t)h->n_reads + ns, MateEntry{0, 0, 0, 0});
       h->mate_dirty = true;
     }
-    if (int rc = scan_slice(h, b, i0, i1, spans, simple, boff, qoff, (uint32_t)h->blob_used, nthreads)) return rc;
-    Staging* st = nullptr;
-    if (int rc = acquire_stage(h, &st)) return rc;
+    if (int rc = scan_slice(h, S, i0, i1, spans, simple, boff, qoff, (uint32_t)h->blob_used, nthreads)) return rc;
     const uint32_t blob_base = (uint32_t)h->blob_used;
-    std::atomic<int64_t> algo(0);
-    const size_t chunk = 4096;
-    const auto t_pack = std::chrono::steady_clock::now();
-    parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
-      int64_t local = 0;
-      for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
-        const int64_t i = i0 + (int64_t)k;
-        ReadCore& rc = st->cores[k];
-        const uint32_t n_cigar = b->n_cigar[i], l = plen(b->l_seq[i]);
-        rc.pos = b->pos[i];
-        rc.flags = b->flags[i];
-        rc.mapq = b->mapq[i];
-        const int strand = strand_of(b->ref_id[i], b->mate_ref_id[i], b->flags[i]);
-        const bool keep = ((uint32_t)h->o.flag_exclude & b->flags[i]) == 0 && (int32_t)b->mapq[i] >= h->o.mapq &&
-                          n_cigar != 0 &&
-                          (h->o.strand_req != BP_STRAND_NONE ? strand == h->o.strand_req
-                                                             : (strand != 0 || h->o.ignore_strand));
-        rc.aux = (uint8_t)((simple[k] ? AUX_SIMPLE : 0) |
-                           (b->ref_id[i] == b->mate_ref_id[i] ? AUX_MATE_SAME : 0) | (keep ? AUX_KEEP : 0) |
-                           (strand << AUX_STRAND_SHIFT));
-        rc.n_cigar = (uint16_t)n_cigar;
-        rc.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
-        rc.l_seq = (uint16_t)std::min<uint32_t>(b->l_seq[i], 0xffffu);
-        rc.qdelta = (uint16_t)((qoff[k] - boff[k]) / 8);
-        rc.blob = blob_base + (uint32_t)(boff[k] / 8);
-        for (uint32_t c = 0; c < 3; c++) rc.cig[c] = c < n_cigar ? b->cigar[b->cigar_off[i] + c] : 0u;
-        uint8_t* d = st->blob + boff[k];
-        const uint32_t ncp = (n_cigar + 1) & ~1u;
-        memcpy(d, b->cigar + b->cigar_off[i], (size_t)n_cigar * 4);
-        if (ncp != n_cigar) memset(d + (size_t)n_cigar * 4, 0, 4);
-        d += (size_t)ncp * 4;
-        const uint32_t U = blob_units(l);
-        uint8_t* dq = st->blob + qoff[k];
-        memcpy(dq, b->qual + b->qual_off[i], l);
-        memset(dq + l, 0, (size_t)U * 8 - l);
-        const uint32_t sb = (l + 1) / 2;
-        // device layout keeps the first base of a byte in the LOW nibble (BAM: high), so 8
-        // bases are one little-endian dword with base k at bits 4k
-        {
-          const uint8_t* sp = b->seq + b->seq_off[i];
-          for (uint32_t x = 0; x < sb; x++) d[x] = (uint8_t)((sp[x] << 4) | (sp[x] >> 4));
-        }
-        const uint64_t tail = base_part_bytes(n_cigar, l) - (uint64_t)ncp * 4 - sb;
-        memset(d + sb, 0, (size_t)tail);
-        local += 32 + 4 * (int64_t)n_cigar + ((int64_t)b->l_seq[i] + 1) / 2 + b->l_seq[i];
-      }
-      algo.fetch_add(local);
-    });
-    h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
-    h->algo_in_bytes += algo.load();
-    // device capacity, then async copies
+    // what the record-level tests come to under the job's options (ReadCore.aux)
+    auto aux_of = [&](int64_t i, size_t k) {
+      const int strand = strand_of(S.ref_id[i], S.mate_ref_id[i], S.flags[i]);
+      const bool keep = ((uint32_t)h->o.flag_exclude & S.flags[i]) == 0 && (int32_t)S.mapq[i] >= h->o.mapq &&
+                        S.n_cigar[i] != 0 &&
+                        (h->o.strand_req != BP_STRAND_NONE ? strand == h->o.strand_req
+                                                           : (strand != 0 || h->o.ignore_strand));
+      return (uint8_t)((simple[k] ? AUX_SIMPLE : 0) | (S.ref_id[i] == S.mate_ref_id[i] ? AUX_MATE_SAME : 0) |
+                       (keep ? AUX_KEEP : 0) | (strand << AUX_STRAND_SHIFT));
+    };
     if (int rc = ensure(h, h->d_cores, ((size_t)h->n_reads + ns) * sizeof(ReadCore), (size_t)h->n_reads * sizeof(ReadCore))) return rc;
     if (int rc = ensure(h, h->d_blob, ((size_t)h->blob_used) * 8 + bytes + 64, (size_t)h->blob_used * 8)) return rc;
-    HIP_TRY(h, hipMemcpyAsync((ReadCore*)h->d_cores.p + h->n_reads, st->cores, ns * sizeof(ReadCore),
-                              hipMemcpyHostToDevice, h->stream));
-    if (bytes)
-      HIP_TRY(h, hipMemcpyAsync((uint8_t*)h->d_blob.p + (size_t)h->blob_used * 8, st->blob, bytes,
+    std::atomic<int64_t> algo(0);
+    const size_t chunk = 4096;
+    Staging* st = nullptr;
+    if (stream_mode) {
+      // The record bytes go to the device as they are and are packed there (pack_kernels.hip).
+      // Straight out of the caller's memory when that is pinned and most of the run is wanted;
+      // else the wanted records are first gathered into pinned staging.
+      const uint64_t first = S.off[i0], extent = (uint64_t)S.off[i1 - 1] + S.rec_bytes[i1 - 1] - first;
+      if (extent > 0xffffffffull) return fail(h, BP_EINVAL, "%s: records spread over more than 4 GiB", who);
+      uint64_t wanted = 0;
+      for (int64_t i = i0; i < i1; i++) wanted += S.rec_bytes[i];
+      const bool direct = pinned_src && wanted * 4 >= extent * 3;
+      if (int rc = acquire_stage(h, &st, true, direct ? 0 : (size_t)wanted)) return rc;
+      const uint64_t shipped = direct ? extent : wanted;
+      if (int rc = ensure(h, h->d_raw, (size_t)shipped + 64, 0)) return rc;
+      if (int rc = ensure(h, h->d_pack, ns * sizeof(PackItem), 0)) return rc;
+      const auto t_pack = std::chrono::steady_clock::now();
+      if (direct) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_raw.p, S.raw + first, (size_t)extent, hipMemcpyHostToDevice, h->stream));
+        wait_for_copy = true;
+      } else {
+        gsrc.resize(ns);
+        uint64_t at = 0;
+        for (size_t k = 0; k < ns; k++) {
+          gsrc[k] = (uint32_t)at;
+          at += S.rec_bytes[i0 + (int64_t)k];
+        }
+      }
+      parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
+        int64_t local = 0;
+        for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
+          const int64_t i = i0 + (int64_t)k;
+          PackItem& it = st->items[k];
+          it.src = direct ? (uint32_t)(S.off[i] - first) : gsrc[k];
+          if (!direct) memcpy(st->raw + gsrc[k], S.raw + S.off[i], S.rec_bytes[i]);
+          it.blob = blob_base + (uint32_t)(boff[k] / 8);
+          it.qdelta = (uint16_t)((qoff[k] - boff[k]) / 8);
+          it.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
+          it.aux = aux_of(i, k);
+          it.l_name = S.l_name[i];
+          it.pad = 0;
+          local += 32 + 4 * (int64_t)S.n_cigar[i] + ((int64_t)S.l_seq[i] + 1) / 2 + S.l_seq[i];
+        }
+        algo.fetch_add(local);
+      });
+      h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
+      if (!direct)
+        HIP_TRY(h, hipMemcpyAsync(h->d_raw.p, st->raw, (size_t)wanted, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->d_pack.p, st->items, ns * sizeof(PackItem), hipMemcpyHostToDevice, h->stream));
+      launch_pack((const uint8_t*)h->d_raw.p, (const PackItem*)h->d_pack.p, (int64_t)ns, (ReadCore*)h->d_cores.p + h->n_reads,
+                  (uint8_t*)h->d_blob.p, h->stream);
+      HIP_TRY(h, hipGetLastError());
+    } else {
+      const bp_record_batch* b = S.b;
+      if (int rc = acquire_stage(h, &st, false, 0)) return rc;
+      const auto t_pack = std::chrono::steady_clock::now();
+      parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
+        int64_t local = 0;
+        for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
+          const int64_t i = i0 + (int64_t)k;
+          ReadCore& rc = st->cores[k];
+          const uint32_t n_cigar = b->n_cigar[i], l = plen(b->l_seq[i]);
+          rc.pos = b->pos[i];
+          rc.flags = b->flags[i];
+          rc.mapq = b->mapq[i];
+          rc.aux = aux_of(i, k);
+          rc.n_cigar = (uint16_t)n_cigar;
+          rc.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
+          rc.l_seq = (uint16_t)std::min<uint32_t>(b->l_seq[i], 0xffffu);
+          rc.qdelta = (uint16_t)((qoff[k] - boff[k]) / 8);
+          rc.blob = blob_base + (uint32_t)(boff[k] / 8);
+          for (uint32_t c = 0; c < 3; c++) rc.cig[c] = c < n_cigar ? b->cigar[b->cigar_off[i] + c] : 0u;
+          uint8_t* d = st->blob + boff[k];
+          const uint32_t ncp = (n_cigar + 1) & ~1u;
+          memcpy(d, b->cigar + b->cigar_off[i], (size_t)n_cigar * 4);
+          if (ncp != n_cigar) memset(d + (size_t)n_cigar * 4, 0, 4);
+          d += (size_t)ncp * 4;
+          const uint32_t U = blob_units(l);
+          uint8_t* dq = st->blob + qoff[k];
+          memcpy(dq, b->qual + b->qual_off[i], l);
+          memset(dq + l, 0, (size_t)U * 8 - l);
+          const uint32_t sb = (l + 1) / 2;
+          // device layout keeps the first base of a byte in the LOW nibble (BAM: high), so 8
+          // bases are one little-endian dword with base k at bits 4k
+          {
+            const uint8_t* sp = b->seq + b->seq_off[i];
+            for (uint32_t x = 0; x < sb; x++) d[x] = (uint8_t)((sp[x] << 4) | (sp[x] >> 4));
+          }
+          const uint64_t tail = base_part_bytes(n_cigar, l) - (uint64_t)ncp * 4 - sb;
+          memset(d + sb, 0, (size_t)tail);
+          local += 32 + 4 * (int64_t)n_cigar + ((int64_t)b->l_seq[i] + 1) / 2 + b->l_seq[i];
+        }
+        algo.fetch_add(local);
+      });
+      h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
+      HIP_TRY(h, hipMemcpyAsync((ReadCore*)h->d_cores.p + h->n_reads, st->cores, ns * sizeof(ReadCore),
                                 hipMemcpyHostToDevice, h->stream));
+      if (bytes)
+        HIP_TRY(h, hipMemcpyAsync((uint8_t*)h->d_blob.p + (size_t)h->blob_used * 8, st->blob, bytes,
+                                  hipMemcpyHostToDevice, h->stream));
+    }
+    h->algo_in_bytes += algo.load();
     HIP_TRY(h, hipEventRecord(st->done, h->stream));
     st->busy = true;
     h->n_reads += (int64_t)ns;
     h->blob_used += bytes / 8;
     i0 = i1;
   }
+  // the caller's memory is the caller's again when the call returns
+  if (wait_for_copy) HIP_TRY(h, hipStreamSynchronize(h->stream));
   poison.armed = false;
   return BP_OK;
+}
+
+int bp_submit(bp_handle* h, const bp_record_batch* b) {
+  if (!h || !b) return fail(h, BP_EINVAL, "bp_submit: null argument");
+  Src S;
+  S.n = b->n;
+  S.ref_id = b->ref_id;
+  S.pos = b->pos;
+  S.mate_ref_id = b->mate_ref_id;
+  S.mate_pos = b->mate_pos;
+  S.flags = b->flags;
+  S.mapq = b->mapq;
+  S.n_cigar = b->n_cigar;
+  S.l_seq = b->l_seq;
+  S.b = b;
+  return submit_records(h, S, "bp_submit");
+}
+
+int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32_t* rec_off, int64_t n) {
+  if (!h || n < 0 || (n > 0 && (!bam || !rec_off))) return fail(h, BP_EINVAL, "bp_submit_bam: bad argument");
+  if (n_bytes > 0xffffffffull) return fail(h, BP_EINVAL, "bp_submit_bam: more than 4 GiB in one call");
+  // The fixed fields of every record (SAM spec 4.2; gbam.Unmarshal, encoding/bam/unmarshal.go:126-224)
+  // into columns, on all packing threads; a record that does not fit its block, or the bytes
+  // given, is refused before anything of the call is taken.
+  const size_t N = (size_t)n;
+  h->x_ref.resize(N); h->x_pos.resize(N); h->x_mref.resize(N); h->x_mpos.resize(N);
+  h->x_flags.resize(N); h->x_mapq.resize(N); h->x_lname.resize(N);
+  h->x_ncig.resize(N); h->x_lseq.resize(N); h->x_bytes.resize(N);
+  std::atomic<int64_t> bad(-1);
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t chunk = 8192;
+  parallel_for((N + chunk - 1) / chunk, pack_threads(), [&](size_t c) {
+    for (size_t k = c * chunk; k < std::min(N, (c + 1) * chunk); k++) {
+      const uint64_t at = rec_off[k];
+      const uint64_t lim = k + 1 < N ? rec_off[k + 1] : n_bytes;  // records in stream order, not overlapping
+      uint32_t w[9];
+      bool ok = at + 36 <= lim && lim <= n_bytes;
+      if (ok) {
+        memcpy(w, bam + at, 36);
+        const uint32_t block_size = w[0], l_name = w[3] & 0xffu, n_cigar = w[4] & 0xffffu, l_seq = w[5];
+        const uint64_t need = 32 + (uint64_t)l_name + 4 * (uint64_t)n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+        ok = block_size >= 32 && need <= block_size && at + 4 + block_size <= lim;
+        if (ok) {
+          h->x_ref[k] = (int32_t)w[1];
+          h->x_pos[k] = (int32_t)w[2];
+          h->x_lname[k] = (uint8_t)l_name;
+          h->x_mapq[k] = (uint8_t)((w[3] >> 8) & 0xffu);
+          h->x_ncig[k] = n_cigar;
+          h->x_flags[k] = (uint16_t)(w[4] >> 16);
+          h->x_lseq[k] = l_seq;
+          h->x_mref[k] = (int32_t)w[6];
+          h->x_mpos[k] = (int32_t)w[7];
+          h->x_bytes[k] = 4 + block_size;
+        }
+      }
+      if (!ok) {
+        int64_t cur = bad.load();
+        while ((cur < 0 || (int64_t)k < cur) && !bad.compare_exchange_weak(cur, (int64_t)k)) {}
+        return;
+      }
+    }
+  });
+  h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (bad.load() >= 0)
+    return fail(h, BP_EINVAL, "bp_submit_bam: record %lld (offset %u) does not fit its block or the bytes given",
+                (long long)bad.load(), rec_off[bad.load()]);
+  Src S;
+  S.n = n;
+  S.ref_id = h->x_ref.data();
+  S.pos = h->x_pos.data();
+  S.mate_ref_id = h->x_mref.data();
+  S.mate_pos = h->x_mpos.data();
+  S.flags = h->x_flags.data();
+  S.mapq = h->x_mapq.data();
+  S.n_cigar = h->x_ncig.data();
+  S.l_seq = h->x_lseq.data();
+  S.raw = bam;
+  S.off = rec_off;
+  S.l_name = h->x_lname.data();
+  S.rec_bytes = h->x_bytes.data();
+  return submit_records(h, S, "bp_submit_bam");
 }
 
 constexpr int32_t kSliceRecs = 2048;  // records per slice of a deep window
@@ -1465,12 +1652,14 @@ void bp_destroy(bp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf* b : {&h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_tile_lo, &h->d_pr_feat, &h->d_seq8, &h->d_refname, &h->d_txt_len, &h->d_txt_tile, &h->d_txt_out, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
+  for (DevBuf* b : {&h->d_raw, &h->d_pack, &h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_tile_lo, &h->d_pr_feat, &h->d_seq8, &h->d_refname, &h->d_txt_len, &h->d_txt_tile, &h->d_txt_out, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
     b->release();
   for (Staging& s : h->stage) {
     if (s.cores) (void)hipHostFree(s.cores);
     if (s.blob) (void)hipHostFree(s.blob);
+    if (s.items) (void)hipHostFree(s.items);
+    if (s.raw) (void)hipHostFree(s.raw);
     if (s.done) (void)hipEventDestroy(s.done);
   }
   for (hipEvent_t e : h->ev)

@@ -101,6 +101,14 @@ class PileupJob:
         cb = batch.as_c()
         self._check(self.lib.bp_submit(self.h, C.byref(cb)))
 
+    def submit_bam(self, stream, rec_off):
+        """records as they lie in an inflated BAM stream (uint8 array) + the offset of each one's
+        block_size field (uint32 array): packed on the device (bp_submit_bam)"""
+        stream = np.ascontiguousarray(stream, np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, np.uint32)
+        self._check(self.lib.bp_submit_bam(self.h, stream.ctypes.data, stream.size,
+                                           rec_off.ctypes.data_as(C.POINTER(C.c_uint32)), rec_off.size))
+
     def finish(self):
         self._check(self.lib.bp_finish(self.h))
 

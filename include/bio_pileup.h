@@ -140,6 +140,18 @@ int bp_set_bed(bp_handle* h, int32_t ref_id, const int32_t* endpoints, int32_t n
  * pileup.go:673-689).  Copies the batch into pinned staging and starts the H2D copy. */
 int bp_submit(bp_handle* h, const bp_record_batch* batch);
 
+/* The same for records as they lie in an inflated BAM stream: what gbam.Unmarshal
+ * (encoding/bam/unmarshal.go:126-224) decodes for the iterator of bamprovider.go:417-435, done
+ * here on the device.  Record k starts - with its block_size field - at bam + rec_off[k];
+ * rec_off ascends, records do not overlap and end at or before n_bytes (at most 4 GiB a call).
+ * The host reads only the fixed fields, CIGARs and (with stitch) names; the bytes are copied to
+ * the GPU as they are - straight from `bam` when that is pinned host memory and at least three
+ * quarters of [first record, last record] are wanted, else gathered into pinned staging first -
+ * and a kernel packs them.  `bam` is the caller's again when the call returns.  Calls may be mixed
+ * with bp_submit within a job.  A record that does not fit its block_size or the bytes given fails
+ * the call (BP_EINVAL) before anything of it is taken. */
+int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32_t* rec_off, int64_t n);
+
 /* finishRef + w.Finish (pileup.go:624-639, :934-938): no more records; computes every
  * row.  Blocks until the rows are resident on the device. */
 int bp_finish(bp_handle* h);

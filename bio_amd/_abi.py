@@ -75,7 +75,7 @@ EXPORTS = [
 HOST_EXPORTS = [
     "bio_pileup_default_opts", "bio_pileup_run", "bio_pileup_main", "bio_parse_region",
     "bio_parse_cols", "bio_bed_load", "bio_bed_endpoints", "bio_bed_intersects", "bio_bed_free",
-    "bio_fasta_seq8", "bio_bam_scan", "bio_bam_seek_scan", "bio_bam_write",
+    "bio_fasta_seq8", "bio_bam_scan", "bio_bam_scan_chunks", "bio_bam_seek_scan", "bio_bam_write",
     "bio_pileup_write_rows", "bio_pileup_row_fields", "bio_marshal_pileup_row", "bio_unmarshal_pileup_row",
     "bio_marshal_basestrand", "bio_unmarshal_basestrand", "bio_basestrand_rio_trailer",
     "bio_parse_basestrand_rio_trailer", "bio_basestrand_piles_to_tsv",
@@ -210,6 +210,10 @@ def load():
     lib.bio_bam_scan.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64), C.POINTER(C.c_int32)] + E
     lib.bio_bam_scan.restype = C.c_int
+    lib.bio_bam_scan_chunks.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int64)] + E
+    lib.bio_bam_scan_chunks.restype = C.c_int
     lib.bio_bam_seek_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]

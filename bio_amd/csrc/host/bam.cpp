@@ -4,14 +4,21 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <future>
+#include <memory>
+#include <mutex>
 #include <thread>
 
+#include "../par.h"
 #include "bio_host.h"
 
 namespace bio {
@@ -76,216 +83,418 @@ const Deflate& GetDeflate() {
   return d;
 }
 
-constexpr int kBatchBlocks = 256;  // up to 16 MiB inflated per refill (8 and 64 MiB are slower)
+constexpr int kBatchBlocksMax = 256;  // up to 16 MiB inflated per refill (8 and 64 MiB are slower)
+int BatchBlocks() {  // BIO_PILEUP_BATCH_BLOCKS exists for tests of the chunk hand-over and the seeks
+  const char* e = getenv("BIO_PILEUP_BATCH_BLOCKS");
+  long v = e && *e ? atol(e) : 0;
+  return v >= 1 && v <= kBatchBlocksMax ? (int)v : kBatchBlocksMax;
+}
 // A batch's inflated bytes start kHead bytes into its buffer: the unconsumed tail of the previous
-// batch (normally part of one record) is copied in front of them and the buffers are swapped,
-// instead of appending 16 MiB to the old one.
+// batch (normally part of one record) is copied in front of them, instead of appending 16 MiB to
+// the old buffer.
 constexpr size_t kHead = 1 << 20;
+constexpr size_t kStdCap = kHead + (size_t)kBatchBlocksMax * 65536 + 64;
+
+// Inflated bytes live in buffers of one size that go back to a pool when the last chunk that
+// points into them is dropped: fresh 17 MiB allocations would be page-faulted in over and over
+// (as much CPU time as inflating them), and pinned ones (hipHostMalloc, so the device can copy
+// records straight out of them: bp_submit_bam) are expensive to make.
+struct Buf {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+};
+
+class BufPool {
+ public:
+  static BufPool& Get() {
+    static BufPool* g = new BufPool();  // never destroyed: chunks may outlive every reader
+    return *g;
+  }
+  std::shared_ptr<Buf> Take(size_t need, bool pinned) {
+    Buf* b = nullptr;
+    if (need <= kStdCap) {
+      std::lock_guard<std::mutex> lk(mu_);
+      std::vector<Buf*>& f = free_[pinned ? 1 : 0];
+      if (!f.empty()) {
+        b = f.back();
+        f.pop_back();
+      }
+    }
+    if (!b) {
+      b = new Buf();
+      b->cap = std::max(need, kStdCap);
+      // only standard buffers are worth pinning (the others hold one over-long record)
+      if (pinned && need <= kStdCap) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, b->cap, hipHostMallocPortable) == hipSuccess) {
+          b->p = (uint8_t*)hp;
+          b->pinned = true;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+      if (!b->p) b->p = (uint8_t*)malloc(b->cap);
+      if (!b->p) {
+        delete b;
+        return nullptr;
+      }
+    }
+    return std::shared_ptr<Buf>(b, [this](Buf* x) { Give(x); });
+  }
+
+ private:
+  void Give(Buf* b) {
+    if (b->cap == kStdCap) {
+      std::lock_guard<std::mutex> lk(mu_);
+      std::vector<Buf*>& f = free_[b->pinned ? 1 : 0];
+      if (f.size() < 24) {
+        f.push_back(b);
+        return;
+      }
+    }
+    if (b->pinned) (void)hipHostFree(b->p);
+    else free(b->p);
+    delete b;
+  }
+  std::mutex mu_;
+  std::vector<Buf*> free_[2];
+};
+}  // namespace
+
+namespace {
+
+// What one walk leaves: the records it passed and what their fixed fields say.
+struct Walk {
+  size_t start = SIZE_MAX;  // where it began (SIZE_MAX: no start found)
+  size_t exit = 0;          // where it stopped: the first record start it did not take
+  bool stopped = false;     // ... because that record is cut off by the end of the buffer or has an invalid block size
+  std::vector<uint32_t> off;
+  bool fields_ok = true, sorted = true, one_ref = true;
+  int32_t r0 = 0, p0 = 0, r1 = 0, p1 = 0;
+};
+
+inline uint64_t OrderKey(int32_t ref, int32_t pos) { return ((uint64_t)(uint32_t)ref << 32) | (uint32_t)pos; }
+
+// Takes whole records from p on while they start before `stop`.
+void WalkFrom(const uint8_t* base, size_t p, size_t stop, size_t end, Walk* w) {
+  w->start = p;
+  w->off.clear();
+  w->stopped = false;
+  w->fields_ok = w->sorted = w->one_ref = true;
+  uint64_t last = 0;
+  while (p < stop) {
+    if (end - p < 4) { w->stopped = true; break; }
+    uint32_t f[6];
+    if (end - p >= 24) memcpy(f, base + p, 24);
+    else f[0] = U32(base + p);
+    const uint32_t bs = f[0];
+    if (bs < 32 || end - p - 4 < bs) { w->stopped = true; break; }
+    __builtin_prefetch(base + p + 2048);
+    const uint64_t need = 32 + (uint64_t)(f[3] & 0xffu) + 4 * (uint64_t)(f[4] & 0xffffu) + ((uint64_t)f[5] + 1) / 2 + f[5];
+    if (need > bs) w->fields_ok = false;
+    const int32_t ref = (int32_t)f[1], pos = (int32_t)f[2];
+    const uint64_t key = OrderKey(ref, pos);  // (unplaced records, ref -1, sort last)
+    if (w->off.empty()) {
+      w->r0 = ref;
+      w->p0 = pos;
+    } else {
+      if (key < last) w->sorted = false;
+      if (ref != w->r0) w->one_ref = false;
+    }
+    last = key;
+    w->r1 = ref;
+    w->p1 = pos;
+    w->off.push_back((uint32_t)p);
+    p += 4 + (size_t)bs;
+  }
+  w->exit = p;
+}
+
+// Could a record start at p?  Only ever a guess (see NextChunk): block size, reference ids,
+// positions and name length in range, the fields inside the block, the name NUL-terminated.
+bool Plausible(const uint8_t* base, size_t p, size_t end, int32_t n_ref) {
+  if (end - p < 36) return false;
+  uint32_t f[8];
+  memcpy(f, base + p, 32);
+  const uint32_t bs = f[0], l_name = f[3] & 0xffu, n_cigar = f[4] & 0xffffu, l_seq = f[5];
+  if (bs < 32 || bs > (1u << 26)) return false;
+  const int32_t ref = (int32_t)f[1], pos = (int32_t)f[2], mref = (int32_t)f[6], mpos = (int32_t)f[7];
+  if (ref < -1 || ref >= n_ref || mref < -1 || mref >= n_ref || pos < -1 || mpos < -1 || l_name == 0) return false;
+  const uint64_t need = 32 + (uint64_t)l_name + 4 * (uint64_t)n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+  if (need > bs) return false;
+  const size_t nul = p + 36 + l_name - 1;
+  return nul >= end || base[nul] == 0;
+}
+
 }  // namespace
 
 struct BamReader::Impl {
   FILE* f = nullptr;
   bool file_eof = false;     // the batch reader met the end of the file
-  std::vector<uint8_t, NoInitAlloc<uint8_t>> buf;  // inflated bytes not yet consumed: [rd, buf.size())
-  size_t rd = 0;
+  bool pinned = false;       // inflate into pinned host memory
+  std::shared_ptr<Buf> cur;  // inflated bytes not yet consumed: cur->p[rd, end)
+  size_t rd = 0, end = 0;
   uint64_t file_pos = 0;  // file offset of the next byte fread returns
   double wait_s = 0;      // time the consumer waited for inflated batches
-  // (offset in buf, file offset) of the blocks buf holds bytes of, ascending
+  // (offset in cur, file offset) of the blocks cur holds bytes of, ascending
   std::vector<std::pair<size_t, uint64_t>> marks;
+  std::vector<Walk> walks;  // NextChunk's, kept for their vectors
 
-  // One batch of BGZF blocks, read and inflated off the main thread while the records of the
-  // previous batch are decoded.
-  struct Batch {
-    std::vector<uint8_t, NoInitAlloc<uint8_t>> data;  // (sized, then filled by the inflaters: not zeroed first)
-    std::vector<std::pair<size_t, uint64_t>> marks;  // (offset in data, file offset)
+  // One batch of BGZF blocks goes through two stages off the main thread, each a batch ahead of
+  // the next: its bytes are read from the file and its block headers parsed (one thread: a memcpy
+  // out of the page cache, a third of a second per GB), then its blocks are inflated (all threads).
+  struct RawBatch {
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> raw;  // file bytes from `at` on
+    struct Blk { size_t off, clen, isize, out; };    // deflate data at raw[off, off + clen), crc32 behind it; inflates to `out`
+    std::vector<Blk> blks;
+    std::vector<std::pair<size_t, uint64_t>> marks;  // (offset in the inflated buffer, file offset)
+    size_t out_total = 0;
     bool eof = false;
     uint64_t end_pos = 0;  // file offset behind the batch
     std::string err;
   };
-  std::future<std::unique_ptr<Batch>> next;
+  struct Batch {
+    std::shared_ptr<Buf> buf;  // inflated bytes at buf->p[kHead, size)
+    size_t size = kHead;
+    std::vector<std::pair<size_t, uint64_t>> marks;
+    bool eof = false;
+    uint64_t end_pos = 0;
+    std::string err;
+  };
+  std::future<std::unique_ptr<Batch>> next;         // the batch behind the one being consumed: inflating or inflated
+  std::future<std::unique_ptr<RawBatch>> next_raw;  // the one behind that: being read (touched by next's task and, once that is done, Seek)
+  uint64_t raw_pos = 0;                             // where the read after next_raw starts (likewise)
+  size_t est_bytes = 0;                             // compressed size of the last batch read
+  std::mutex spare_mu;
+  std::vector<std::unique_ptr<RawBatch>> spare;     // RawBatches to use again (their vectors' memory is already faulted in)
 
   ~Impl() {
     if (next.valid()) next.wait();
+    if (next_raw.valid()) next_raw.wait();
     if (f) fclose(f);
   }
 
-  std::unique_ptr<Batch> ReadBatch(uint64_t at) {
-    std::unique_ptr<Batch> out(new Batch);
-    Batch& B = *out;
-    struct Blk { size_t off, clen, isize, out; };
-    std::vector<Blk> blks;
-    std::vector<uint8_t, NoInitAlloc<uint8_t>> raw;
-    size_t out_total = 0;
-    uint64_t pos = at;
-    while ((int)blks.size() < kBatchBlocks) {
-      uint8_t hd[18];
-      const uint64_t block_at = pos;
-      size_t got = fread(hd, 1, 18, f);
-      if (got == 0) { B.eof = true; break; }
-      if (got != 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) {
-        B.err = "bgzf: invalid block header";
-        return out;
+  std::unique_ptr<RawBatch> ReadRaw(uint64_t at) {
+    std::unique_ptr<RawBatch> out;
+    {
+      std::lock_guard<std::mutex> lk(spare_mu);
+      if (!spare.empty()) {
+        out = std::move(spare.back());
+        spare.pop_back();
       }
-      unsigned xlen = U16(hd + 10);
-      // The BC subfield is first in every BGZF writer in use; handle the general case too.
-      std::vector<uint8_t> extra(xlen);
-      memcpy(extra.data(), hd + 12, std::min<size_t>(6, xlen));
-      if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != xlen - 6) { B.err = "bgzf: truncated block"; return out; }
-      int bsize = -1;
-      for (size_t p = 0; p + 4 <= extra.size();) {
-        unsigned slen = U16(extra.data() + p + 2);
-        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= extra.size())
-          bsize = U16(extra.data() + p + 4);
-        p += 4 + slen;
-      }
-      if (bsize < 0) { B.err = "bgzf: missing BC subfield"; return out; }
-      long total = (long)bsize + 1;
-      long remaining = total - 12 - (long)xlen;  // deflate data + crc32 + isize
-      if (xlen < 6 || remaining < 8) { B.err = "bgzf: invalid block size"; return out; }
-      size_t off = raw.size();
-      raw.resize(off + (size_t)remaining);
-      if (fread(raw.data() + off, 1, (size_t)remaining, f) != (size_t)remaining) { B.err = "bgzf: truncated block"; return out; }
-      size_t isize = U32(raw.data() + off + (size_t)remaining - 4);
-      if (isize > 65536) { B.err = "bgzf: invalid uncompressed size"; return out; }
-      blks.push_back({off, (size_t)remaining - 8, isize, kHead + out_total});
-      if (isize) B.marks.emplace_back(kHead + out_total, block_at);
-      pos = block_at + (uint64_t)total;
-      out_total += isize;
     }
-    B.end_pos = pos;
-    B.data.resize(kHead + out_total);
-    if (blks.empty()) return out;
-    int nt = std::min<int>(HostThreads(), (int)blks.size());
-    std::vector<int> bad((size_t)nt, 0);
-    const Deflate& ld = GetDeflate();
-    auto work = [&](int t) {
-      z_stream zs;
-      void* dec = ld.ok ? ld.alloc() : nullptr;
-      struct FreeDec { const Deflate& d; void* p; ~FreeDec() { if (p) d.free_(p); } } free_dec{ld, dec};
-      for (size_t i = (size_t)t; i < blks.size(); i += (size_t)nt) {
-        const Blk& b = blks[i];
-        if (b.isize == 0) continue;
-        if (dec) {
-          size_t got = 0;
-          if (ld.decompress(dec, raw.data() + b.off, b.clen, B.data.data() + b.out, b.isize, &got) != 0 || got != b.isize ||
-              ld.crc32_(0, B.data.data() + b.out, b.isize) != U32(raw.data() + b.off + b.clen)) {
-            bad[(size_t)t] = 1;
-            return;
-          }
-          continue;
-        }
-        memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
-        zs.next_in = raw.data() + b.off;
-        zs.avail_in = (uInt)b.clen;
-        zs.next_out = B.data.data() + b.out;
-        zs.avail_out = (uInt)b.isize;
-        int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
-        if (rc != Z_STREAM_END || zs.avail_out != 0) { bad[(size_t)t] = 1; return; }
-        uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), B.data.data() + b.out, (uInt)b.isize);
-        if (crc != U32(raw.data() + b.off + b.clen)) { bad[(size_t)t] = 1; return; }
+    if (!out) out.reset(new RawBatch);
+    RawBatch& B = *out;
+    B.blks.clear();
+    B.marks.clear();
+    B.out_total = 0;
+    B.eof = false;
+    B.err.clear();
+    const int fd = fileno(f);
+    const int batch_blocks = BatchBlocks();
+    size_t have = 0;
+    bool file_end = false;
+    auto read_more = [&](size_t want) {  // appends up to `want` file bytes
+      if (B.raw.size() < have + want) B.raw.resize(have + want);
+      while (want && !file_end) {
+        ssize_t got = pread(fd, B.raw.data() + have, want, (off_t)(at + have));
+        if (got < 0) { B.err = "bgzf: read failed"; file_end = true; break; }
+        if (got == 0) { file_end = true; break; }
+        have += (size_t)got;
+        want -= (size_t)got;
       }
     };
-    if (nt == 1) {
-      work(0);
-    } else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nt; t++) th.emplace_back(work, t);
-      for (auto& x : th) x.join();
+    read_more(est_bytes ? est_bytes + est_bytes / 16 + 65536 : (size_t)batch_blocks * 20480 + 65536);
+    size_t p = 0;
+    while ((int)B.blks.size() < batch_blocks && B.err.empty()) {
+      // the fixed part of the header and the length of the extra field
+      if (have - p < 18 && !file_end) read_more(1 << 20);
+      if (have == p) { B.eof = true; break; }
+      const uint8_t* hd = B.raw.data() + p;
+      if (have - p < 18 || hd[0] != 31 || hd[1] != 139 || hd[2] != 8 || !(hd[3] & 4)) {
+        B.err = "bgzf: invalid block header";
+        break;
+      }
+      const unsigned xlen = U16(hd + 10);
+      if (have - p < 12 + (size_t)xlen && !file_end) read_more(1 << 20);
+      if (have - p < 12 + (size_t)xlen) { B.err = "bgzf: truncated block"; break; }
+      hd = B.raw.data() + p;
+      // The BC subfield is first in every BGZF writer in use; handle the general case too.
+      const uint8_t* extra = hd + 12;
+      int bsize = -1;
+      for (size_t q = 0; q + 4 <= xlen;) {
+        unsigned slen = U16(extra + q + 2);
+        if (extra[q] == 'B' && extra[q + 1] == 'C' && slen == 2 && q + 6 <= xlen) bsize = U16(extra + q + 4);
+        q += 4 + slen;
+      }
+      if (bsize < 0) { B.err = "bgzf: missing BC subfield"; break; }
+      const size_t total = (size_t)bsize + 1;
+      const long remaining = (long)total - 12 - (long)xlen;  // deflate data + crc32 + isize
+      if (xlen < 6 || remaining < 8) { B.err = "bgzf: invalid block size"; break; }
+      if (have - p < total && !file_end) read_more(std::max<size_t>(1 << 20, total));
+      if (have - p < total) { B.err = "bgzf: truncated block"; break; }
+      const size_t isize = U32(B.raw.data() + p + total - 4);
+      if (isize > 65536) { B.err = "bgzf: invalid uncompressed size"; break; }
+      B.blks.push_back({p + 12 + xlen, (size_t)remaining - 8, isize, kHead + B.out_total});
+      if (isize) B.marks.emplace_back(kHead + B.out_total, at + p);
+      p += total;
+      B.out_total += isize;
     }
-    for (int b : bad)
-      if (b) { B.err = "bgzf: corrupt block (inflate or CRC failure)"; break; }
+    B.end_pos = at + p;
+    if (p) est_bytes = p;
     return out;
   }
 
-  // Appends the next batch behind the unconsumed tail and starts reading the one after it.
-  std::string Refill() {
-    if (!file_eof && buf.size() - rd <= kHead) {
-      const auto w0 = std::chrono::steady_clock::now();
-      std::unique_ptr<Batch> b = next.valid() ? next.get() : ReadBatch(file_pos);
-      wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-      if (!b->err.empty()) return b->err;
-      const size_t tail = buf.size() - rd, at = kHead - tail;
-      if (tail) memcpy(b->data.data() + at, buf.data() + rd, tail);
-      // the mark of the block the tail starts in, and later ones, move with it
-      std::vector<std::pair<size_t, uint64_t>> nm;
-      if (tail) {
-        size_t k = 0;
-        while (k + 1 < marks.size() && marks[k + 1].first <= rd) k++;
-        for (; k < marks.size(); k++) nm.emplace_back((marks[k].first > rd ? marks[k].first - rd : 0) + at, marks[k].second);
-      }
-      nm.insert(nm.end(), b->marks.begin(), b->marks.end());
-      marks.swap(nm);
-      buf.swap(b->data);
-      rd = at;
-      file_pos = b->end_pos;
-      file_eof = b->eof;
-      if (!file_eof) {
-        const uint64_t pos = file_pos;
-        next = std::async(std::launch::async, [this, pos] { return ReadBatch(pos); });
-      }
-      return "";
+  std::unique_ptr<Batch> Inflate(std::unique_ptr<RawBatch> in) {
+    std::unique_ptr<Batch> out(new Batch);
+    Batch& B = *out;
+    RawBatch& R = *in;
+    B.err = R.err;
+    B.eof = R.eof;
+    B.end_pos = R.end_pos;
+    B.marks.swap(R.marks);
+    if (!B.err.empty()) return out;
+    B.buf = BufPool::Get().Take(kHead + R.out_total, pinned);
+    if (!B.buf) { B.err = "bam: out of memory"; return out; }
+    B.size = kHead + R.out_total;
+    if (!R.blks.empty()) {
+      uint8_t* const dst = B.buf->p;
+      const uint8_t* const raw = R.raw.data();
+      const std::vector<RawBatch::Blk>& blks = R.blks;
+      const Deflate& ld = GetDeflate();
+      std::atomic<int> bad(0);
+      // a few blocks per task: the pool's threads take them as they come free
+      constexpr size_t kPer = 4;
+      bp_par::parallel_for((blks.size() + kPer - 1) / kPer, HostThreads(), [&](size_t c) {
+        // (a thread keeps its decompressor as long as it lives)
+        thread_local struct Dec { void* p = nullptr; ~Dec() { if (p) GetDeflate().free_(p); } } tl;
+        if (ld.ok && !tl.p) tl.p = ld.alloc();
+        void* const dec = tl.p;
+        for (size_t i = c * kPer; i < std::min(blks.size(), (c + 1) * kPer); i++) {
+          const RawBatch::Blk& b = blks[i];
+          if (b.isize == 0) continue;
+          if (dec) {
+            size_t got = 0;
+            if (ld.decompress(dec, raw + b.off, b.clen, dst + b.out, b.isize, &got) != 0 || got != b.isize ||
+                ld.crc32_(0, dst + b.out, b.isize) != U32(raw + b.off + b.clen))
+              bad = 1;
+            continue;
+          }
+          z_stream zs;
+          memset(&zs, 0, sizeof(zs));
+          if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
+          zs.next_in = const_cast<uint8_t*>(raw + b.off);
+          zs.avail_in = (uInt)b.clen;
+          zs.next_out = dst + b.out;
+          zs.avail_out = (uInt)b.isize;
+          int rc = inflate(&zs, Z_FINISH);
+          inflateEnd(&zs);
+          if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; continue; }
+          uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), dst + b.out, (uInt)b.isize);
+          if (crc != U32(raw + b.off + b.clen)) bad = 1;
+        }
+      });
+      if (bad) B.err = "bgzf: corrupt block (inflate or CRC failure)";
     }
-    if (rd > 0) {
-      buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)rd);
-      // keep the mark of the block the tail starts in (its offset becomes 0) and later ones
+    std::lock_guard<std::mutex> lk(spare_mu);
+    if (spare.size() < 3) spare.push_back(std::move(in));
+    return out;
+  }
+
+  // The batch at raw_pos: its bytes are being read already (next_raw) or are read now; the read
+  // of the batch behind it is started before this one is inflated.
+  std::unique_ptr<Batch> NextBatch() {
+    std::unique_ptr<RawBatch> r = next_raw.valid() ? next_raw.get() : ReadRaw(raw_pos);
+    raw_pos = r->end_pos;
+    if (r->err.empty() && !r->eof) {
+      const uint64_t pos = raw_pos;
+      next_raw = std::async(std::launch::async, [this, pos] { return ReadRaw(pos); });
+    }
+    return Inflate(std::move(r));
+  }
+
+  // Brings in the next batch behind the unconsumed tail and starts reading the one after it.
+  std::string Refill() {
+    if (file_eof) return "";
+    const auto w0 = std::chrono::steady_clock::now();
+    std::unique_ptr<Batch> b = next.valid() ? next.get() : NextBatch();
+    wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    if (!b->err.empty()) return b->err;
+    const size_t tail = end - rd;
+    std::shared_ptr<Buf> nb = b->buf;
+    size_t at, nend;
+    ptrdiff_t shift;  // of the batch's marks
+    if (tail <= kHead) {
+      at = kHead - tail;
+      if (tail) memcpy(nb->p + at, cur->p + rd, tail);
+      nend = b->size;
+      shift = 0;
+    } else {
+      // a record longer than kHead: tail and batch side by side in a buffer of their own
+      nb = BufPool::Get().Take(tail + (b->size - kHead), false);
+      if (!nb) return "bam: out of memory";
+      memcpy(nb->p, cur->p + rd, tail);
+      memcpy(nb->p + tail, b->buf->p + kHead, b->size - kHead);
+      at = 0;
+      nend = tail + (b->size - kHead);
+      shift = (ptrdiff_t)tail - (ptrdiff_t)kHead;
+    }
+    // the mark of the block the tail starts in, and later ones, move with it
+    std::vector<std::pair<size_t, uint64_t>> nm;
+    if (tail) {
       size_t k = 0;
       while (k + 1 < marks.size() && marks[k + 1].first <= rd) k++;
-      marks.erase(marks.begin(), marks.begin() + (ptrdiff_t)k);
-      for (auto& mk : marks) mk.first = mk.first > rd ? mk.first - rd : 0;
-      rd = 0;
+      for (; k < marks.size(); k++) nm.emplace_back((marks[k].first > rd ? marks[k].first - rd : 0) + at, marks[k].second);
     }
-    if (file_eof) return "";
-    std::unique_ptr<Batch> b = next.valid() ? next.get() : ReadBatch(file_pos);
-    if (!b->err.empty()) return b->err;
-    const size_t base = buf.size();  // (a record longer than kHead: the slow way)
-    buf.insert(buf.end(), b->data.begin() + (ptrdiff_t)std::min(kHead, b->data.size()), b->data.end());
-    for (const auto& mk : b->marks) marks.emplace_back(base + mk.first - kHead, mk.second);
+    for (const auto& mk : b->marks) nm.emplace_back((size_t)((ptrdiff_t)mk.first + shift), mk.second);
+    marks.swap(nm);
+    cur = nb;
+    rd = at;
+    end = nend;
     file_pos = b->end_pos;
     file_eof = b->eof;
-    if (!file_eof) {
-      const uint64_t at = file_pos;
-      next = std::async(std::launch::async, [this, at] { return ReadBatch(at); });
-    }
+    if (!file_eof) next = std::async(std::launch::async, [this] { return NextBatch(); });
     return "";
   }
 
   // Makes at least n unconsumed bytes available; returns false at a clean or short EOF.
   bool Need(size_t n, std::string* err) {
-    while (buf.size() - rd < n) {
+    while (end - rd < n) {
       if (file_eof) return false;
       *err = Refill();
       if (!err->empty()) return false;
     }
     return true;
   }
+  const uint8_t* at() const { return cur->p + rd; }
 };
 
 BamReader::BamReader() : impl_(new Impl) {}
 BamReader::~BamReader() {}
 
+void BamReader::SetPinned(bool on) { impl_->pinned = on; }
+
 std::string BamReader::Open(const std::string& path) {
   impl_->f = fopen(path.c_str(), "rb");
   if (!impl_->f) return "open " + path + ": no such file or directory";
-  setvbuf(impl_->f, nullptr, _IOFBF, 4 << 20);
   std::string err;
   Impl& m = *impl_;
   if (!m.Need(12, &err)) return err.empty() ? "bam: truncated header" : err;
-  if (memcmp(m.buf.data() + m.rd, "BAM\1", 4) != 0) return "bam: magic number mismatch";
-  uint32_t l_text = U32(m.buf.data() + m.rd + 4);
+  if (memcmp(m.at(), "BAM\1", 4) != 0) return "bam: magic number mismatch";
+  uint32_t l_text = U32(m.at() + 4);
   if (!m.Need(12 + (size_t)l_text, &err)) return err.empty() ? "bam: truncated header" : err;
-  header_.text.assign((const char*)m.buf.data() + m.rd + 8, l_text);
+  header_.text.assign((const char*)m.at() + 8, l_text);
   while (!header_.text.empty() && header_.text.back() == '\0') header_.text.pop_back();
-  uint32_t n_ref = U32(m.buf.data() + m.rd + 8 + l_text);
+  uint32_t n_ref = U32(m.at() + 8 + l_text);
   m.rd += 12 + (size_t)l_text;
   for (uint32_t i = 0; i < n_ref; i++) {
     if (!m.Need(4, &err)) return err.empty() ? "bam: truncated header" : err;
-    uint32_t l_name = U32(m.buf.data() + m.rd);
+    uint32_t l_name = U32(m.at());
     if (!m.Need(8 + (size_t)l_name, &err)) return err.empty() ? "bam: truncated header" : err;
-    std::string nm((const char*)m.buf.data() + m.rd + 4, l_name ? l_name - 1 : 0);
+    std::string nm((const char*)m.at() + 4, l_name ? l_name - 1 : 0);
     header_.ref_names.push_back(nm);
-    header_.ref_lens.push_back(I32(m.buf.data() + m.rd + 4 + l_name));
+    header_.ref_lens.push_back(I32(m.at() + 4 + l_name));
     m.rd += 8 + (size_t)l_name;
   }
   return "";
@@ -294,16 +503,16 @@ std::string BamReader::Open(const std::string& path) {
 std::string BamReader::Seek(uint64_t voffset) {
   Impl& m = *impl_;
   const uint64_t coff = voffset >> 16;
-  if (m.next.valid()) m.next.get();  // the reader thread owns the file until its batch is done
-  if (fseeko(m.f, (off_t)coff, SEEK_SET) != 0) return "bgzf: seek failed";
-  m.file_pos = coff;
+  // what is being read and inflated ahead is dropped
+  if (m.next.valid()) m.next.get();
+  if (m.next_raw.valid()) m.next_raw.get();
+  m.file_pos = m.raw_pos = coff;
   m.file_eof = false;
-  m.buf.clear();
-  m.rd = 0;
+  m.rd = m.end = 0;  // (chunks handed out keep their buffer; the reader lets go of it at the refill)
   m.marks.clear();
   std::string err = m.Refill();
   if (!err.empty()) return err;
-  if ((voffset & 0xffff) > m.buf.size() - m.rd) return "bgzf: virtual offset past the end of its block";
+  if ((voffset & 0xffff) > m.end - m.rd) return "bgzf: virtual offset past the end of its block";
   m.rd += (size_t)(voffset & 0xffff);
   return "";
 }
@@ -322,30 +531,14 @@ double BamReader::WaitSeconds() const { return impl_->wait_s; }
 
 bool BamReader::NextRefills() const {
   const Impl& m = *impl_;
-  const size_t have = m.buf.size() - m.rd;
+  const size_t have = m.end - m.rd;
   if (have < 4) return true;
-  return have < 4 + (size_t)U32(m.buf.data() + m.rd);
+  return have < 4 + (size_t)U32(m.at());
 }
 
-int BamReader::Next(Raw* r) {
-  Impl& m = *impl_;
-  std::string err;
-  if (!m.Need(4, &err)) {
-    if (!err.empty()) { err_ = err; return -1; }
-    if (m.buf.size() != m.rd) { err_ = "bam: truncated record"; return -1; }
-    return 0;
-  }
-  uint32_t block_size = U32(m.buf.data() + m.rd);
-  if (block_size < 32) { err_ = "bam: invalid record block size"; return -1; }
-  if (!m.Need(4 + (size_t)block_size, &err)) {
-    err_ = err.empty() ? "bam: truncated record" : err;
-    return -1;
-  }
-  const uint8_t* p = m.buf.data() + m.rd + 4;
-  m.rd += 4 + (size_t)block_size;
-  // The walk is a pointer chase (a record's length says where the next one starts) through
-  // bytes another core has just inflated: pull the lines a few records ahead in now.
-  for (int k = 0; k < 5; k++) __builtin_prefetch(p + 1024 + 64 * k);
+bool BamReader::Parse(const uint8_t* rec, Raw* r) {
+  const uint32_t block_size = U32(rec);
+  const uint8_t* p = rec + 4;
   r->ref_id = I32(p);
   r->pos = I32(p + 4);
   uint32_t l_read_name = p[8];
@@ -356,7 +549,7 @@ int BamReader::Next(Raw* r) {
   r->mate_ref_id = I32(p + 20);
   r->mate_pos = I32(p + 24);
   size_t need = 32 + (size_t)l_read_name + 4 * (size_t)r->n_cigar + ((size_t)r->l_seq + 1) / 2 + r->l_seq;
-  if (need > block_size) { err_ = "bam: record fields exceed block size"; return -1; }
+  if (need > block_size) return false;
   r->name = (const char*)p + 32;
   r->l_name = l_read_name ? l_read_name - 1 : 0;
   r->cigar = (const uint32_t*)(p + 32 + l_read_name);  // read with memcpy by callers
@@ -364,6 +557,122 @@ int BamReader::Next(Raw* r) {
   r->qual = r->seq + ((size_t)r->l_seq + 1) / 2;
   r->aux = r->qual + r->l_seq;
   r->l_aux = (uint32_t)(block_size - need);
+  return true;
+}
+
+// The first record of what is buffered, whole: 1; clean end of the file: 0; else -1.
+static int FirstRecord(BamReader::Impl& m, std::string* err_out) {
+  std::string err;
+  if (!m.Need(4, &err)) {
+    if (!err.empty()) { *err_out = err; return -1; }
+    if (m.end != m.rd) { *err_out = "bam: truncated record"; return -1; }
+    return 0;
+  }
+  uint32_t block_size = U32(m.at());
+  if (block_size < 32) { *err_out = "bam: invalid record block size"; return -1; }
+  if (!m.Need(4 + (size_t)block_size, &err)) {
+    *err_out = err.empty() ? "bam: truncated record" : err;
+    return -1;
+  }
+  return 1;
+}
+
+int BamReader::Next(Raw* r) {
+  Impl& m = *impl_;
+  int rc = FirstRecord(m, &err_);
+  if (rc <= 0) return rc;
+  const uint8_t* rec = m.at();
+  m.rd += 4 + (size_t)U32(rec);
+  // The walk is a pointer chase (a record's length says where the next one starts) through
+  // bytes another core has just inflated: pull the lines a few records ahead in now.
+  for (int k = 0; k < 5; k++) __builtin_prefetch(rec + 1028 + 64 * k);
+  if (!Parse(rec, r)) { err_ = "bam: record fields exceed block size"; return -1; }
+  return 1;
+}
+
+// The records of a buffer are a chain (a record's block size says where the next one starts), and
+// walking it alone costs a cache miss per record on bytes other cores have just inflated: 35 ns x
+// 50 M records for a 30x chr1.  So the buffer is cut into one stretch per thread; each thread but
+// the first GUESSES where a record starts in its stretch (the first offset behind the cut where a
+// record and the two behind it look like records) and walks on from there to the next cut, noting
+// offsets and surveying fields as it goes.  The guesses are then checked in order: stretch j+1's
+// start is right iff it is where stretch j's walk - right by induction from the known start of
+// the buffer - came out.  A wrong or missing guess costs a second walk of that stretch from the
+// right place; it never changes the result.
+int BamReader::NextChunk(Chunk* c) {
+  Impl& m = *impl_;
+  c->off.clear();
+  int rc = FirstRecord(m, &err_);
+  if (rc <= 0) return rc;
+  const uint8_t* base = m.cur->p;
+  const size_t lo = m.rd, end = m.end;
+  const int32_t n_ref = (int32_t)header_.ref_lens.size();
+  constexpr size_t kMinStretch = 256 << 10;
+  const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, HostThreads()), (end - lo) / kMinStretch));
+  std::vector<Walk>& ws = m.walks;
+  if (ws.size() < T + 1) ws.resize(T + 1);
+  auto cut = [&](size_t j) { return j >= T ? end : lo + (end - lo) / T * j; };
+  bp_par::parallel_for(T, (int)T, [&](size_t j) {
+    Walk& w = ws[j];
+    size_t p = lo;
+    if (j > 0) {
+      p = SIZE_MAX;
+      // a record start lies within one record length of the cut: look a little further than any sane record is long
+      const size_t from = cut(j), upto = std::min(end, from + (64 << 10));
+      for (size_t q = from; q < upto; q++) {
+        if (!Plausible(base, q, end, n_ref)) continue;
+        size_t q2 = q + 4 + U32(base + q);
+        if (q2 + 36 <= end) {
+          if (!Plausible(base, q2, end, n_ref)) continue;
+          const size_t q3 = q2 + 4 + U32(base + q2);
+          if (q3 + 36 <= end && !Plausible(base, q3, end, n_ref)) continue;
+        }
+        p = q;
+        break;
+      }
+      if (p == SIZE_MAX) {
+        w.start = SIZE_MAX;
+        return;
+      }
+    }
+    WalkFrom(base, p, cut(j + 1), end, &w);
+  });
+  // check the guesses in order; the chunk ends where a walk stopped
+  size_t at = lo;
+  bool first = true;
+  uint64_t last_key = 0;
+  Walk& redo = ws[T];
+  c->fields_ok = c->sorted = c->one_ref = true;
+  c->rewalked = 0;
+  for (size_t j = 0; j < T; j++) {
+    if (at >= cut(j + 1)) continue;  // a long record carried the chain past this stretch
+    Walk* w = &ws[j];
+    if (w->start != at) {
+      WalkFrom(base, at, cut(j + 1), end, &redo);
+      w = &redo;
+      c->rewalked++;
+    }
+    if (!w->off.empty()) {
+      c->off.insert(c->off.end(), w->off.begin(), w->off.end());
+      c->fields_ok &= w->fields_ok;
+      c->sorted &= w->sorted && (first || OrderKey(w->r0, w->p0) >= last_key);
+      if (first) {
+        c->first_ref = w->r0;
+        c->first_pos = w->p0;
+      }
+      c->one_ref &= w->one_ref && w->r0 == c->first_ref;
+      c->last_ref = w->r1;
+      c->last_pos = w->p1;
+      last_key = OrderKey(w->r1, w->p1);
+      first = false;
+    }
+    at = w->exit;
+    if (w->stopped) break;
+  }
+  c->hold = m.cur;
+  c->data = base;
+  c->bytes = at;
+  m.rd = at;
   return 1;
 }
 

@@ -101,6 +101,29 @@ class BamReader {
     const uint8_t* aux; uint32_t l_aux;
   };
   int Next(Raw* r);
+  // The fields of the record whose block_size field is at `rec` (all of the record's bytes
+  // must be there); false when they do not fit the block size.
+  static bool Parse(const uint8_t* rec, Raw* r);
+  // All whole records that are buffered, as they lie in the inflated stream: record k starts
+  // (block_size field) at data + off[k], and all of them end at or before data + bytes.  The
+  // memory stays valid for as long as `hold` is kept, whatever the reader does next.  Same
+  // return values as Next(); fields are only surveyed (Parse checks one record's).
+  struct Chunk {
+    std::shared_ptr<const void> hold;
+    const uint8_t* data = nullptr;
+    size_t bytes = 0;
+    std::vector<uint32_t> off;
+    // what the walk saw in the fixed fields of these records:
+    bool fields_ok = true;  // every record's fields fit its block
+    bool sorted = true;     // (ref, pos) never descends inside the chunk (ref -1 sorts last)
+    bool one_ref = true;    // every record lies on first_ref
+    int32_t first_ref = -1, first_pos = 0, last_ref = -1, last_pos = 0;
+    int rewalked = 0;       // stretches whose guessed start was wrong (walked again from the right place)
+  };
+  int NextChunk(Chunk* c);
+  // Inflate into pinned host memory (hipHostMalloc), which bp_submit_bam copies from without
+  // staging.  Before Open().
+  void SetPinned(bool on);
   // True when the next Next() has to bring in more of the file first: the buffers move then,
   // and the pointers of Raw records handed out so far stop being valid.
   bool NextRefills() const;
@@ -113,8 +136,9 @@ class BamReader {
   // File offset of the BGZF block the next record starts in.
   uint64_t BlockOffset() const;
 
+ struct Impl;
+
  private:
-  struct Impl;
   std::unique_ptr<Impl> impl_;
   BamHeader header_;
   std::string err_;

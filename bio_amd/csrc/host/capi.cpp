@@ -154,6 +154,70 @@ int bio_bam_scan(const char* path, int64_t* n_records, int64_t* sum_l_seq, int64
   return Ok(err, errlen);
 }
 
+int bio_bam_scan_chunks(const char* path, int64_t* n_records, int64_t* n_chunks, uint64_t* hash_records,
+                        uint64_t* hash_chunks, int32_t* sorted, int32_t* fields_ok, int64_t* n_rewalked, char* err,
+                        size_t errlen) {
+  auto mix = [](uint64_t h, const bio::BamReader::Raw& r) {
+    const uint64_t v[3] = {((uint64_t)(uint32_t)r.ref_id << 32) | (uint32_t)r.pos, ((uint64_t)r.l_seq << 32) | r.n_cigar,
+                           ((uint64_t)r.flags << 32) | r.l_name};
+    for (uint64_t x : v) h = (h ^ x) * 0x100000001b3ull;
+    return h;
+  };
+  // record by record
+  uint64_t h1 = 0xcbf29ce484222325ull, h2 = h1;
+  int64_t n1 = 0, n2 = 0, nc = 0, nrw = 0;
+  {
+    bio::BamReader rd;
+    std::string m = rd.Open(Str(path));
+    if (!m.empty()) return Fail(m, err, errlen);
+    bio::BamReader::Raw r;
+    int rc;
+    while ((rc = rd.Next(&r)) == 1) {
+      h1 = mix(h1, r);
+      n1++;
+    }
+    if (rc < 0) return Fail(rd.err(), err, errlen);
+  }
+  // a chunk at a time (stretches walked in parallel from guessed starts, guesses checked)
+  bool all_sorted = true, all_ok = true;
+  {
+    bio::BamReader rd;
+    std::string m = rd.Open(Str(path));
+    if (!m.empty()) return Fail(m, err, errlen);
+    bio::BamReader::Chunk c;
+    int rc;
+    uint64_t last = 0;
+    while ((rc = rd.NextChunk(&c)) == 1) {
+      nc++;
+      nrw += c.rewalked;
+      bool srt = true, ok = true;
+      for (size_t k = 0; k < c.off.size(); k++) {
+        bio::BamReader::Raw r;
+        if (!bio::BamReader::Parse(c.data + c.off[k], &r)) ok = false;
+        h2 = mix(h2, r);
+        n2++;
+        const uint64_t key = ((uint64_t)(uint32_t)r.ref_id << 32) | (uint32_t)r.pos;
+        if (k && key < last) srt = false;
+        last = key;
+      }
+      // the facts the walk reports are the facts of the records
+      if (srt != c.sorted || ok != c.fields_ok) return Fail("bio_bam_scan_chunks: chunk facts disagree with its records", err, errlen);
+      all_sorted &= srt;
+      all_ok &= ok;
+    }
+    if (rc < 0) return Fail(rd.err(), err, errlen);
+  }
+  if (n1 != n2) return Fail("bio_bam_scan_chunks: record counts differ", err, errlen);
+  if (n_records) *n_records = n1;
+  if (n_chunks) *n_chunks = nc;
+  if (hash_records) *hash_records = h1;
+  if (hash_chunks) *hash_chunks = h2;
+  if (sorted) *sorted = all_sorted ? 1 : 0;
+  if (fields_ok) *fields_ok = all_ok ? 1 : 0;
+  if (n_rewalked) *n_rewalked = nrw;
+  return Ok(err, errlen);
+}
+
 int bio_bam_seek_scan(const char* bam_path, const char* index_path, int32_t ref_id, int32_t pos, int32_t* found,
                       int32_t* first_ref, int32_t* first_pos, int64_t* n_skipped, int64_t* n_at_or_after, char* err,
                       size_t errlen) {

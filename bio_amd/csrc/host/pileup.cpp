@@ -24,21 +24,13 @@
 #include <cstring>
 #include <deque>
 
+#include "../par.h"
 #include "bio_host.h"
 
 namespace bio {
 
 namespace {
 
-constexpr int64_t kSubmitRecordsDefault = 1 << 20;  // records per bp_submit
-int64_t SubmitRecords() {  // BIO_PILEUP_SUBMIT_RECORDS exists for tests of the batch hand-over
-  const char* e = getenv("BIO_PILEUP_SUBMIT_RECORDS");
-  if (e && *e) {
-    long long v = atoll(e);
-    if (v > 0) return v;
-  }
-  return kSubmitRecordsDefault;
-}
 constexpr int64_t kRowChunk = 1 << 20;       // rows per bp_rows copy
 // With an index, stretches of the BAM that start more than this many positions before the
 // next padded BED interval are skipped (the reference's position shards are this long, and
@@ -115,101 +107,14 @@ struct Stream {  // one output stream = one strand pass (pileup.go:1118-1128)
 
 std::string HandleErr(bp_handle* h) { return bp_last_error(h); }
 
-void AppendRecord(RecordBatchBuilder* b, const BamReader::Raw& r) {
-  b->ref_id.push_back(r.ref_id);
-  b->pos.push_back(r.pos);
-  b->mate_ref_id.push_back(r.mate_ref_id);
-  b->mate_pos.push_back(r.mate_pos);
-  b->flags.push_back(r.flags);
-  b->mapq.push_back(r.mapq);
-  b->n_cigar.push_back(r.n_cigar);
-  b->l_seq.push_back(r.l_seq);
-  b->cigar_off.push_back(b->cigar.size());
-  size_t o = b->cigar.size();
-  b->cigar.resize(o + r.n_cigar);
-  if (r.n_cigar) memcpy(b->cigar.data() + o, r.cigar, 4 * (size_t)r.n_cigar);
-  b->seq_off.push_back(b->seq.size());
-  b->seq.insert(b->seq.end(), r.seq, r.seq + ((size_t)r.l_seq + 1) / 2);
-  b->qual_off.push_back(b->qual.size());
-  b->qual.insert(b->qual.end(), r.qual, r.qual + r.l_seq);
-  if (b->keep_names) {
-    b->name_off.push_back(b->name.size());
-    b->name.insert(b->name.end(), (const uint8_t*)r.name, (const uint8_t*)r.name + r.l_name);
-  }
-}
-
-// The same for a run of records whose bytes still sit in the reader's buffer: offsets by one
-// serial pass, the copies on HostThreads() threads.
-void AppendRecords(RecordBatchBuilder* b, const std::vector<BamReader::Raw>& raws) {
-  const size_t m = raws.size();
-  if (m < 4096) {
-    for (const BamReader::Raw& r : raws) AppendRecord(b, r);
-    return;
-  }
-  const size_t n0 = (size_t)b->size();
-  size_t co = b->cigar.size(), so = b->seq.size(), qo = b->qual.size(), no = b->name.size();
-  b->cigar_off.resize(n0 + m);
-  b->seq_off.resize(n0 + m);
-  b->qual_off.resize(n0 + m);
-  if (b->keep_names) b->name_off.resize(n0 + m);
-  for (size_t i = 0; i < m; i++) {
-    const BamReader::Raw& r = raws[i];
-    b->cigar_off[n0 + i] = co;
-    b->seq_off[n0 + i] = so;
-    b->qual_off[n0 + i] = qo;
-    co += r.n_cigar;
-    so += ((size_t)r.l_seq + 1) / 2;
-    qo += r.l_seq;
-    if (b->keep_names) {
-      b->name_off[n0 + i] = no;
-      no += r.l_name;
-    }
-  }
-  b->ref_id.resize(n0 + m);
-  b->pos.resize(n0 + m);
-  b->mate_ref_id.resize(n0 + m);
-  b->mate_pos.resize(n0 + m);
-  b->flags.resize(n0 + m);
-  b->mapq.resize(n0 + m);
-  b->n_cigar.resize(n0 + m);
-  b->l_seq.resize(n0 + m);
-  b->cigar.resize(co);
-  b->seq.resize(so);
-  b->qual.resize(qo);
-  if (b->keep_names) b->name.resize(no);
-  constexpr size_t kChunk = 2048;
-  const size_t n_chunks = (m + kChunk - 1) / kChunk;
-  const size_t nt = std::min<size_t>((size_t)std::max(1, HostThreads()), n_chunks);
-  auto work = [&](size_t t) {
-    for (size_t c = t; c < n_chunks; c += nt) {
-      for (size_t i = c * kChunk; i < std::min(m, (c + 1) * kChunk); i++) {
-        const BamReader::Raw& r = raws[i];
-        const size_t k = n0 + i;
-        b->ref_id[k] = r.ref_id;
-        b->pos[k] = r.pos;
-        b->mate_ref_id[k] = r.mate_ref_id;
-        b->mate_pos[k] = r.mate_pos;
-        b->flags[k] = r.flags;
-        b->mapq[k] = r.mapq;
-        b->n_cigar[k] = r.n_cigar;
-        b->l_seq[k] = r.l_seq;
-        if (r.n_cigar) memcpy(b->cigar.data() + b->cigar_off[k], r.cigar, 4 * (size_t)r.n_cigar);
-        if (r.l_seq) {
-          memcpy(b->seq.data() + b->seq_off[k], r.seq, ((size_t)r.l_seq + 1) / 2);
-          memcpy(b->qual.data() + b->qual_off[k], r.qual, r.l_seq);
-        }
-        if (b->keep_names && r.l_name) memcpy(b->name.data() + b->name_off[k], r.name, r.l_name);
-      }
-    }
-  };
-  if (nt <= 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; t++) th.emplace_back(work, t);
-    for (auto& x : th) x.join();
-  }
-}
+// The records of one chunk of the inflated stream that one job wants: the bytes stay where the
+// reader inflated them (pinned memory) and go to the device from there (bp_submit_bam).
+struct Piece {
+  std::shared_ptr<const void> hold;
+  const uint8_t* data = nullptr;
+  size_t bytes = 0;
+  std::vector<uint32_t> off;
+};
 
 class Driver {
  public:
@@ -283,12 +188,10 @@ class Driver {
     return "";
   }
 
-  std::string Submit(RecordBatchBuilder* b) {
-    if (b->size() == 0) return "";
-    bp_record_batch v = b->view();
+  std::string SubmitPiece(const Piece& p) {
+    if (p.off.empty()) return "";
     for (Stream& s : streams)
-      if (bp_submit(s.h, &v) != BP_OK) return HandleErr(s.h);
-    b->clear();
+      if (bp_submit_bam(s.h, p.data, p.bytes, p.off.data(), (int64_t)p.off.size()) != BP_OK) return HandleErr(s.h);
     return "";
   }
 
@@ -501,6 +404,73 @@ class Closer {
   std::thread th_;
 };
 
+// The open job's pieces go to the device (bp_submit_bam: host scan, copy, pack kernel) on a
+// thread of their own, in order, while the main thread walks the next chunk.
+class Submitter {
+ public:
+  explicit Submitter(Driver* d) : drv_(d), th_([this] { Run(); }) {}
+  ~Submitter() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_ = true;
+      cv_.notify_all();
+    }
+    if (th_.joinable()) th_.join();
+  }
+  // Blocks while three pieces are already waiting; returns the first error so far.
+  std::string Push(Piece&& p) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return q_.size() < 3; });
+    if (err_.empty()) {
+      q_.push_back(std::move(p));
+      cv_.notify_all();
+    }
+    return err_;
+  }
+  // Every piece pushed so far has been submitted (or dropped after an error).
+  std::string Drain() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return q_.empty() && !working_; });
+    return err_;
+  }
+  double busy_s() const { return busy_s_; }
+
+ private:
+  void Run() {
+    for (;;) {
+      Piece p;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty() || done_; });
+        if (q_.empty()) return;
+        p = std::move(q_.front());
+        q_.pop_front();
+        working_ = true;
+        cv_.notify_all();
+      }
+      const double t0 = Now();
+      std::string e = drv_->SubmitPiece(p);
+      p = Piece();  // the chunk's buffer goes back to the reader's pool
+      busy_s_ += Now() - t0;
+      std::unique_lock<std::mutex> lk(mu_);
+      working_ = false;
+      if (!e.empty() && err_.empty()) {
+        err_ = e;
+        q_.clear();
+      }
+      cv_.notify_all();
+    }
+  }
+  Driver* drv_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Piece> q_;
+  bool done_ = false, working_ = false;
+  std::string err_;
+  double busy_s_ = 0;
+  std::thread th_;
+};
+
 }  // namespace
 
 std::string Pileup(const std::string& xampath, const std::string& fapath, const std::string& format,
@@ -529,6 +499,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   if (xampath.size() >= 4 && xampath.compare(xampath.size() - 4, 4, ".pam") == 0)
     return "Pileup: PAM input is not supported by this build (BAM only)";
   BamReader bam;
+  bam.SetPinned(true);  // the device copies records straight out of the reader's buffers
   {
     std::string err = bam.Open(xampath);
     if (!err.empty()) return err;
@@ -664,56 +635,56 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   drv.SetPadding(opts.Stitch ? pad : 0);
   Stats st;
   const double t_start = Now();
-  std::deque<RecordBatchBuilder> pend(1);
-  pend[0].keep_names = true;  // stitching keys on names; error messages quote them
-  // Records are first only noted (pointers into the reader's buffer), then copied into the
-  // builders many at a time and on several threads, before the reader's buffer moves.
-  std::deque<std::vector<BamReader::Raw>> raw(1);
-  double copy_s = 0;
-  auto flush_raw = [&]() {
-    const double f0 = Now();
-    struct Acc { double* s; double t0; ~Acc() { *s += Now() - t0; } } acc{&copy_s, f0};
-    for (size_t k = 0; k < raw.size(); k++) {
-      if (raw[k].empty()) continue;
-      while (pend.size() <= k) {
-        pend.emplace_back();
-        pend.back().keep_names = true;  // stitching keys on names; error messages quote them
-      }
-      AppendRecords(&pend[k], raw[k]);
-      raw[k].clear();
-    }
-  };
+  // The reader hands out the inflated stream a chunk at a time (all whole records of up to 16 MiB,
+  // in pinned memory).  Nothing is copied on the host: a job gets, per chunk, the list of the
+  // records it wants (a Piece), and the device takes the bytes from the chunk itself.  A chunk
+  // that lies inside one job's range and inside scanned shards - nearly all of a whole-genome run
+  // - is handed over whole on what the reader's walk saw in its fixed fields; other chunks go through
+  // the record-by-record rules below.  pend[k - ji]: pieces job k has been given before it opens.
+  std::deque<std::vector<Piece>> pend(1);
+  std::vector<std::vector<uint32_t>> sel(1);  // of the chunk at hand: records for job ji + k
   size_t ji = 0;
   bool open = false;
   std::string err;
-  auto open_job = [&]() -> std::string {
-    std::string e = drv.OpenJob(jobs[ji]);
-    open = e.empty();
-    return e;
-  };
-  const int64_t submit_records = SubmitRecords();
   CloseGate gate;
   std::vector<std::unique_ptr<Closer>> closers;
   for (size_t k = 0; k < drv.n_closers(); k++) closers.emplace_back(new Closer(&drv, &gate));
-  // A full batch is packed and copied to the device (bp_submit) on a thread of its own while
-  // the main thread goes on reading into the other builder; one batch in flight at most.
-  RecordBatchBuilder inflight;
-  inflight.keep_names = true;
-  std::future<std::string> submitting;
-  auto wait_submit = [&]() -> std::string {
-    if (!submitting.valid()) return "";
-    const double t0 = Now();
-    std::string e = submitting.get();
-    st.submit_s += Now() - t0;
+  Submitter submitter(&drv);
+  auto open_job = [&]() -> std::string {
+    std::string e = drv.OpenJob(jobs[ji]);
+    open = e.empty();
+    // what the job was given while the ones before it were open
+    for (Piece& p : pend[0])
+      if (e.empty()) e = submitter.Push(std::move(p));
+    pend[0].clear();
+    return e;
+  };
+  BamReader::Chunk ck;
+  // The chunk's records chosen so far become pieces: the open job's go to the submitter.
+  auto flush_sel = [&]() -> std::string {
+    std::string e;
+    for (size_t k = 0; k < sel.size(); k++) {
+      if (sel[k].empty()) continue;
+      Piece p;
+      p.hold = ck.hold;
+      p.data = ck.data;
+      p.bytes = ck.bytes;
+      p.off.swap(sel[k]);
+      while (pend.size() <= k) pend.emplace_back();
+      if (k == 0 && open) {
+        if (e.empty()) e = submitter.Push(std::move(p));
+      } else {
+        pend[k].push_back(std::move(p));
+      }
+    }
     return e;
   };
   auto close_job = [&]() -> std::string {
-    flush_raw();
-    if (!raw.empty()) raw.pop_front();
-    if (raw.empty()) raw.emplace_back();
-    std::string e = wait_submit();
+    std::string e = flush_sel();
+    if (!sel.empty()) sel.erase(sel.begin());
+    if (sel.empty()) sel.emplace_back();
     double t0 = Now();
-    if (e.empty()) e = drv.Submit(&pend[0]);
+    if (e.empty()) e = submitter.Drain();
     st.submit_s += Now() - t0;
     t0 = Now();
     if (e.empty()) e = closers[ji % closers.size()]->Push(jobs[ji], drv.TakeHandles(), drv.open_rows);
@@ -722,11 +693,29 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     open = false;
     ji++;
     pend.pop_front();
-    if (pend.empty()) {
-      pend.emplace_back();
-      pend[0].keep_names = true;  // stitching keys on names; error messages quote them
-    }
+    if (pend.empty()) pend.emplace_back();
     return e;
+  };
+  // jobs whose padded range ends at or before (ref, pos) are complete
+  auto close_upto = [&](int32_t ref, int32_t pos) -> std::string {
+    while (ji < jobs.size() && (jobs[ji].ref < ref || (jobs[ji].ref == ref && (int64_t)jobs[ji].end + pad_end <= pos))) {
+      std::string e;
+      if (!open && !(e = open_job()).empty()) return e;
+      if (!(e = close_job()).empty()) return e;
+    }
+    return "";
+  };
+  // jobs behind the front one that also want a record at (ref, pos): those it lies in the padding of
+  auto followers = [&](int32_t ref, int32_t pos) {
+    size_t n = 0;
+    for (size_t k = ji + 1; k < jobs.size() && jobs[k].ref == ref && (int64_t)jobs[k].start - pad <= pos; k++) n++;
+    return n;
+  };
+  // Is the 100 kb position shard that starts at shard0 one the reference scans: does it meet a
+  // padded BED interval [start - pad, end + pad_end)?
+  auto shard_scanned = [&](int32_t ref, int64_t shard0) {
+    return bed.IntersectsByID(ref, (PosType)std::max<int64_t>(0, shard0 - pad_end),
+                              (PosType)std::min<int64_t>(kPosTypeMax, shard0 + kSeekGap + pad));
   };
   BamReader::Raw r;
   int32_t last_ref = -1, last_pos = -1;
@@ -744,89 +733,118 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
       st.seeks++;
     }
   }
-  while (err.empty() && !no_records && ji < jobs.size()) {
-    if (bam.NextRefills()) flush_raw();
-    int rc = bam.Next(&r);
+  bool done = false;
+  while (err.empty() && !no_records && !done && ji < jobs.size()) {
+    int rc = bam.NextChunk(&ck);
     if (rc < 0) { err = bam.err(); break; }
     if (rc == 0) break;
-    st.records_read++;
-    if (r.ref_id < 0) break;  // unplaced reads sort last
-    if (r.ref_id < last_ref || (r.ref_id == last_ref && r.pos < last_pos)) {
-      err = "Pileup: BAM is not coordinate-sorted at " + std::string(r.name, r.l_name);
-      break;
+    const size_t n = ck.off.size();
+    const BamReader::Chunk& cf = ck;  // what the reader's walk saw in the records' fixed fields
+    // ---- the whole chunk at once
+    bool whole = region_ref < 0 && !need_aux && cf.fields_ok && cf.sorted && cf.one_ref && cf.first_ref >= 0 &&
+                 !(cf.first_ref < last_ref || (cf.first_ref == last_ref && cf.first_pos < last_pos)) &&
+                 !(cf.first_ref < skip_ref || (cf.first_ref == skip_ref && cf.first_pos < skip_pos));
+    if (whole)
+      for (int64_t sh = (int64_t)cf.first_pos / kSeekGap * kSeekGap; sh <= cf.last_pos && whole; sh += kSeekGap)
+        whole = shard_scanned(cf.first_ref, sh);
+    if (whole) {
+      if (!(err = close_upto(cf.first_ref, cf.first_pos)).empty()) break;
+      if (ji >= jobs.size()) break;
+      // the last record closes no job and is wanted by the same jobs as the first
+      whole = jobs[ji].ref >= cf.first_ref &&
+              (jobs[ji].ref > cf.first_ref || ((int64_t)jobs[ji].end + pad_end > cf.last_pos &&
+                                               followers(cf.first_ref, cf.first_pos) == followers(cf.first_ref, cf.last_pos)));
     }
-    last_ref = r.ref_id;
-    last_pos = r.pos;
-    if (region_ref >= 0) {  // iterator of the single region shard (bamprovider.go:417-435)
-      if (r.ref_id < region_ref || (r.ref_id == region_ref && r.pos < region.start0)) continue;
-      if (r.ref_id > region_ref || r.pos >= region.end) break;
-    } else {
-      // The reference scans whole 100 kb position shards and only those that meet the padded BED
-      // (bamprovider.go:262-263, pileup_support.go:71-85): a record is scanned - and goes through
-      // the read-length checks - iff its shard does.  The same rule here, index or not: both
-      // ways the device is fed the same records and raises the same errors; the index only saves
-      // reading the rest.
-      if (r.ref_id < skip_ref || (r.ref_id == skip_ref && r.pos < skip_pos)) continue;
-      const int64_t shard0 = (int64_t)r.pos / kSeekGap * kSeekGap;
-      int nref = 0;
-      int64_t nstart = 0;
-      if (!need.Next(r.ref_id, shard0, &nref, &nstart)) break;  // past the last BED interval
-      if (nref != r.ref_id || nstart >= shard0 + kSeekGap) {
-        if (!index.loaded()) continue;
-        const int64_t target = nstart / kSeekGap * kSeekGap;  // the first record of the next shard that is scanned
-        uint64_t voff = 0;
-        if (!index.Offset(nref, (int32_t)target, &voff)) break;  // no records from there on
-        skip_ref = nref;
-        skip_pos = target;
-        if ((voff >> 16) > bam.BlockOffset()) {
-          flush_raw();
-          if (!(err = bam.Seek(voff)).empty()) break;
-          st.seeks++;
-        }
-        continue;
-      }
-    }
-    // jobs whose padded range ends at or before this record are complete
-    while (ji < jobs.size() &&
-           (jobs[ji].ref < r.ref_id || (jobs[ji].ref == r.ref_id && (int64_t)jobs[ji].end + pad_end <= r.pos))) {
+    if (whole) {
+      st.records_read += (int64_t)n;
+      last_ref = cf.last_ref;
+      last_pos = cf.last_pos;
+      if (jobs[ji].ref != cf.first_ref) continue;  // contig without BED positions
       if (!open && !(err = open_job()).empty()) break;
-      if (!(err = close_job()).empty()) break;
+      const size_t nf = followers(cf.first_ref, cf.first_pos);
+      if (sel.size() < nf + 1) sel.resize(nf + 1);
+      for (size_t k = 1; k <= nf; k++) sel[k] = ck.off;
+      sel[0].swap(ck.off);
+      st.records_kept += (int64_t)n;
+      err = flush_sel();
+      continue;
     }
-    if (!err.empty() || ji >= jobs.size()) break;
-    if (jobs[ji].ref != r.ref_id) continue;  // contig without BED positions
-    if (need_aux) {
-      // Same read-level predicate the device applies first (pileup.go:691), so the aux tags
-      // are only demanded of reads the reference would have asked (pileup.go:695-716).
-      if ((opts.FlagExclude & r.flags) || opts.Mapq > (int)r.mapq || r.n_cigar == 0) continue;
-      int64_t v = 0;
-      if (opts.RemoveSq) {
-        if (!AuxInt(r.aux, r.l_aux, "DL", &v)) { err = "sam.Record.LibraryBagSize: no DL aux tag on read " + std::string(r.name, r.l_name); break; }
-        if (v < 2) continue;
+    // ---- record by record
+    for (size_t i = 0; i < n && err.empty(); i++) {
+      const uint8_t* rec = ck.data + ck.off[i];
+      st.records_read++;
+      if (!BamReader::Parse(rec, &r)) { err = "bam: record fields exceed block size"; break; }
+      if (r.ref_id < 0) { done = true; break; }  // unplaced reads sort last
+      if (r.ref_id < last_ref || (r.ref_id == last_ref && r.pos < last_pos)) {
+        err = "Pileup: BAM is not coordinate-sorted at " + std::string(r.name, r.l_name);
+        break;
       }
-      if (opts.MinBagDepth != 0) {
-        if (!AuxInt(r.aux, r.l_aux, "DS", &v)) { err = "sam.Record.BagSize: no DS aux tag on read " + std::string(r.name, r.l_name); break; }
-        if (v < opts.MinBagDepth) continue;
+      last_ref = r.ref_id;
+      last_pos = r.pos;
+      if (region_ref >= 0) {  // iterator of the single region shard (bamprovider.go:417-435)
+        if (r.ref_id < region_ref || (r.ref_id == region_ref && r.pos < region.start0)) continue;
+        if (r.ref_id > region_ref || r.pos >= region.end) { done = true; break; }
+      } else {
+        // The reference scans whole 100 kb position shards and only those that meet the padded BED
+        // (bamprovider.go:262-263, pileup_support.go:71-85): a record is scanned - and goes through
+        // the read-length checks - iff its shard does.  The same rule here, index or not: both
+        // ways the device is fed the same records and raises the same errors; the index only saves
+        // reading the rest.
+        if (r.ref_id < skip_ref || (r.ref_id == skip_ref && r.pos < skip_pos)) continue;
+        const int64_t shard0 = (int64_t)r.pos / kSeekGap * kSeekGap;
+        int nref = 0;
+        int64_t nstart = 0;
+        if (!need.Next(r.ref_id, shard0, &nref, &nstart)) { done = true; break; }  // past the last BED interval
+        if (nref != r.ref_id || nstart >= shard0 + kSeekGap) {
+          if (!index.loaded()) continue;
+          const int64_t target = nstart / kSeekGap * kSeekGap;  // the first record of the next shard that is scanned
+          uint64_t voff = 0;
+          if (!index.Offset(nref, (int32_t)target, &voff)) { done = true; break; }  // no records from there on
+          skip_ref = nref;
+          skip_pos = target;
+          // The reader stands behind this chunk.  A target further on than that lies behind every
+          // record of the chunk too (the index points at or before the first record it is for):
+          // the rest of the chunk is dropped with what the seek skips.
+          if ((voff >> 16) > bam.BlockOffset()) {
+            if (!(err = bam.Seek(voff)).empty()) break;
+            st.seeks++;
+            break;
+          }
+          continue;
+        }
+      }
+      if (!(err = close_upto(r.ref_id, r.pos)).empty()) break;
+      if (ji >= jobs.size()) { done = true; break; }
+      if (jobs[ji].ref != r.ref_id) continue;  // contig without BED positions
+      if (need_aux) {
+        // Same read-level predicate the device applies first (pileup.go:691), so the aux tags
+        // are only demanded of reads the reference would have asked (pileup.go:695-716).
+        if ((opts.FlagExclude & r.flags) || opts.Mapq > (int)r.mapq || r.n_cigar == 0) continue;
+        int64_t v = 0;
+        if (opts.RemoveSq) {
+          if (!AuxInt(r.aux, r.l_aux, "DL", &v)) { err = "sam.Record.LibraryBagSize: no DL aux tag on read " + std::string(r.name, r.l_name); break; }
+          if (v < 2) continue;
+        }
+        if (opts.MinBagDepth != 0) {
+          if (!AuxInt(r.aux, r.l_aux, "DS", &v)) { err = "sam.Record.BagSize: no DS aux tag on read " + std::string(r.name, r.l_name); break; }
+          if (v < opts.MinBagDepth) continue;
+        }
+      }
+      // The front job also takes reads ahead of its padded start: they cannot reach it, but
+      // they go through the library's read checks as they do in whichever reference job
+      // scans them.
+      if (!open && !(err = open_job()).empty()) break;
+      sel[0].push_back(ck.off[i]);
+      st.records_kept++;
+      for (size_t k = ji + 1; k < jobs.size() && jobs[k].ref == r.ref_id && (int64_t)jobs[k].start - pad <= r.pos; k++) {
+        if (sel.size() <= k - ji) sel.resize(k - ji + 1);
+        sel[k - ji].push_back(ck.off[i]);
       }
     }
-    // The front job also takes reads ahead of its padded start: they cannot reach it, but
-    // they go through the library's read checks as they do in whichever reference job
-    // scans them.
-    if (!open && !(err = open_job()).empty()) break;
-    raw[0].push_back(r);
-    st.records_kept++;
-    for (size_t k = ji + 1; k < jobs.size() && jobs[k].ref == r.ref_id && (int64_t)jobs[k].start - pad <= r.pos; k++) {
-      if (raw.size() <= k - ji) raw.emplace_back();
-      raw[k - ji].push_back(r);
-    }
-    if (pend[0].size() + (int64_t)raw[0].size() >= submit_records) {
-      flush_raw();
-      if (!(err = wait_submit()).empty()) break;
-      std::swap(inflight, pend[0]);  // (Submit left the other one empty)
-      submitting = std::async(std::launch::async, [&drv, &inflight] { return drv.Submit(&inflight); });
-    }
+    if (err.empty()) err = flush_sel();
   }
-  if (err.empty()) err = wait_submit();
-  else (void)wait_submit();
+  for (auto& v : sel) v.clear();
+  ck = BamReader::Chunk();
   // jobs after the last record still emit their (zero) rows (flushEmptyContigs,
   // pileup_support.go:112-123)
   while (err.empty() && ji < jobs.size()) {
@@ -835,6 +853,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   }
   {
     const double t0 = Now();
+    (void)submitter.Drain();
     for (auto& c : closers) c->Join();
     st.close_wait_s += Now() - t0;
     for (auto& c : closers) st.close_s += c->busy_s();
@@ -852,11 +871,11 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
-            "submit_s=%.3f close_s=%.3f (on its own thread; the reader waited %.3f s for it) read_s=%.3f "
-            "(of which waiting for inflated blocks %.3f, copying records %.3f) total_s=%.3f\n",
+            "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
+            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) total_s=%.3f\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
-            index.loaded() ? 1 : 0, st.submit_s, st.close_s, st.close_wait_s,
-            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), copy_s, st.total_s);
+            index.loaded() ? 1 : 0, submitter.busy_s(), st.submit_s, st.close_s, st.close_wait_s,
+            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), st.total_s);
   return "";
 }
 

@@ -81,9 +81,13 @@ class Pool {
   void Loop() {
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
+      // the newest loop first: the short loops of the record pipeline wait on their helpers,
+      // while a batch being inflated is a chunk ahead of its reader anyway
       Job* mine = nullptr;
-      for (Job* j : jobs_)
+      for (size_t k = jobs_.size(); k-- > 0;) {
+        Job* j = jobs_[k];
         if (j->joined < j->max_helpers && j->next.load(std::memory_order_relaxed) < j->n) { mine = j; break; }
+      }
       if (!mine) {
         cv_.wait(lk);
         continue;

@@ -274,7 +274,10 @@ struct bp_handle {
   std::vector<uint16_t> x_flags;
   std::vector<uint8_t> x_mapq, x_lname;
   std::vector<uint32_t> x_ncig, x_lseq, x_bytes;
+  std::vector<int32_t> x_span;
+  std::vector<uint8_t> x_cfacts;
   std::vector<uint64_t> scan_hash;
+  double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // BP_PROFILE=1: extract, layout, scan-par, scan-serial, items, ensure, copy wait, total
   double scan_s = 0, pack_s = 0;                      // host time in bp_submit so far: serial scan (order, errors, pairing) / parallel passes
   uint8_t qthr[96];
 
@@ -520,6 +523,8 @@ struct Src {
   const uint32_t* off = nullptr;
   const uint8_t* l_name = nullptr;     // stream mode: l_read_name (with the NUL)
   const uint32_t* rec_bytes = nullptr; // stream mode: 4 + block_size
+  const int32_t* span = nullptr;       // stream mode: cigar_span() of every record, worked out when its fields were read
+  const uint8_t* cig_facts = nullptr;  // ... bit 0 simple, bit 1 has an op outside MIDNSH
 
   const uint8_t* cigar(int64_t i) const {
     return raw ? raw + off[i] + 36 + l_name[i] : (const uint8_t*)(b->cigar + b->cigar_off[i]);
@@ -580,7 +585,14 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
         continue;
       }
       bool simp = false, has_bad = false;
-      const int32_t span = cigar_span(S.cigar(i), n_cigar, &simp, &has_bad);
+      int32_t span;
+      if (S.span) {
+        span = S.span[i];
+        simp = (S.cig_facts[i] & 1) != 0;
+        has_bad = (S.cig_facts[i] & 2) != 0;
+      } else {
+        span = cigar_span(S.cigar(i), n_cigar, &simp, &has_bad);
+      }
       spans[k] = span;
       simple[k] = simp ? 1 : 0;
       const int32_t ref = S.ref_id[i], pos = S.pos[i];
@@ -616,10 +628,15 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
   });
   const auto t_ser = std::chrono::steady_clock::now();
   h->pack_s += std::chrono::duration<double>(t_ser - t_par).count();
+  h->prof[2] += std::chrono::duration<double>(t_ser - t_par).count();
   struct Timer {
     bp_handle* h;
     std::chrono::steady_clock::time_point t0;
-    ~Timer() { h->scan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    ~Timer() {
+      const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      h->scan_s += d;
+      h->prof[3] += d;
+    }
   } timer{h, t_ser};
 
   for (size_t k = 0; k < ns; k++) {
@@ -858,7 +875,18 @@ int bp_set_bed(bp_handle* h, int32_t ref_id, const int32_t* endpoints, int32_t n
 
 // One submit call, either kind.  (Runs between `extern "C" {` and its end: plain C++ linkage is
 // all it needs, it is static.)
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct ProfTimer {
+  double* acc;
+  double t0;
+  explicit ProfTimer(double* a) : acc(a), t0(now_s()) {}
+  ~ProfTimer() { *acc += now_s() - t0; }
+};
+
 static int submit_records(bp_handle* h, const Src& S, const char* who) {
+  ProfTimer prof_total(&h->prof[7]);
   if (h->finished) return fail(h, BP_EINVAL, "%s: called after bp_finish", who);
   if (S.n < 0) return fail(h, BP_EINVAL, "%s: negative record count", who);
   if (h->o.stitch && S.n > 0 && !S.has_names())
@@ -880,7 +908,18 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
   const int nthreads = pack_threads();
   const bool stream_mode = S.raw != nullptr;
   const bool pinned_src = stream_mode && S.n > 0 && host_pinned(S.raw + S.off[0]);
-  bool wait_for_copy = false;  // a copy out of the caller's own memory is in flight
+  // a copy out of the caller's own memory is in flight: the caller's memory is the caller's again
+  // when the call returns, however it returns
+  bool wait_for_copy = false;
+  struct CopyFence {
+    bp_handle* h;
+    bool* armed;
+    ~CopyFence() {
+      if (!*armed) return;
+      ProfTimer pt(&h->prof[6]);
+      (void)hipStreamSynchronize(h->stream);
+    }
+  } copy_fence{h, &wait_for_copy};
   std::vector<int32_t> spans;
   std::vector<uint8_t> simple;
   std::vector<uint64_t> boff, qoff;
@@ -892,6 +931,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
     // slice bounded by staging capacity
     int64_t i1 = i0;
     uint64_t bytes = 0;
+    const double t_layout = now_s();
     boff.clear();
     qoff.clear();
     while (i1 < S.n && (size_t)(i1 - i0) < kStageReads) {
@@ -920,6 +960,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       i1 = g1;
     }
     const size_t ns = (size_t)(i1 - i0);
+    h->prof[1] += now_s() - t_layout;
     if ((uint64_t)h->blob_used + bytes / 8 > 0xffffffffull)
       return fail(h, BP_ENOMEM, "%s: more than 32 GiB of record payload in one job", who);
     if (h->n_reads + (int64_t)ns > 0x7fffffff)
@@ -929,6 +970,46 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
     if (h->o.stitch) {
       h->mate.resize((size_t)h->n_reads + ns, MateEntry{0, 0, 0, 0});
       h->mate_dirty = true;
+    }
+    // The record bytes go to the device as they are and are packed there (pack_kernels.hip):
+    // straight out of the caller's memory when that is pinned and most of the run is wanted, else
+    // the wanted records are first gathered into pinned staging.  The copy is started before the
+    // host scan, which it then runs beside.
+    Staging* st = nullptr;
+    bool direct = false;
+    uint64_t raw_first = 0;
+    if (stream_mode) {
+      const uint64_t extent = (uint64_t)S.off[i1 - 1] + S.rec_bytes[i1 - 1] - S.off[i0];
+      raw_first = S.off[i0];
+      if (extent > 0xffffffffull) return fail(h, BP_EINVAL, "%s: records spread over more than 4 GiB", who);
+      uint64_t wanted = 0;
+      for (int64_t i = i0; i < i1; i++) wanted += S.rec_bytes[i];
+      direct = pinned_src && wanted * 4 >= extent * 3;
+      {
+        ProfTimer pt(&h->prof[5]);
+        if (int rc = acquire_stage(h, &st, true, direct ? 0 : (size_t)wanted)) return rc;
+        if (int rc = ensure(h, h->d_raw, (size_t)(direct ? extent : wanted) + 64, 0)) return rc;
+        if (int rc = ensure(h, h->d_pack, ns * sizeof(PackItem), 0)) return rc;
+      }
+      if (direct) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_raw.p, S.raw + raw_first, (size_t)extent, hipMemcpyHostToDevice, h->stream));
+        wait_for_copy = true;
+      } else {
+        const auto t_g = std::chrono::steady_clock::now();
+        gsrc.resize(ns);
+        uint64_t at = 0;
+        for (size_t k = 0; k < ns; k++) {
+          gsrc[k] = (uint32_t)at;
+          at += S.rec_bytes[i0 + (int64_t)k];
+        }
+        const size_t gchunk = 1024;
+        parallel_for((ns + gchunk - 1) / gchunk, nthreads, [&](size_t c) {
+          for (size_t k = c * gchunk; k < std::min(ns, (c + 1) * gchunk); k++)
+            memcpy(st->raw + gsrc[k], S.raw + S.off[i0 + (int64_t)k], S.rec_bytes[i0 + (int64_t)k]);
+        });
+        h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_g).count();
+        HIP_TRY(h, hipMemcpyAsync(h->d_raw.p, st->raw, (size_t)wanted, hipMemcpyHostToDevice, h->stream));
+      }
     }
     if (int rc = scan_slice(h, S, i0, i1, spans, simple, boff, qoff, (uint32_t)h->blob_used, nthreads)) return rc;
     const uint32_t blob_base = (uint32_t)h->blob_used;
@@ -942,43 +1023,21 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       return (uint8_t)((simple[k] ? AUX_SIMPLE : 0) | (S.ref_id[i] == S.mate_ref_id[i] ? AUX_MATE_SAME : 0) |
                        (keep ? AUX_KEEP : 0) | (strand << AUX_STRAND_SHIFT));
     };
-    if (int rc = ensure(h, h->d_cores, ((size_t)h->n_reads + ns) * sizeof(ReadCore), (size_t)h->n_reads * sizeof(ReadCore))) return rc;
-    if (int rc = ensure(h, h->d_blob, ((size_t)h->blob_used) * 8 + bytes + 64, (size_t)h->blob_used * 8)) return rc;
+    {
+      ProfTimer pt(&h->prof[5]);
+      if (int rc = ensure(h, h->d_cores, ((size_t)h->n_reads + ns) * sizeof(ReadCore), (size_t)h->n_reads * sizeof(ReadCore))) return rc;
+      if (int rc = ensure(h, h->d_blob, ((size_t)h->blob_used) * 8 + bytes + 64, (size_t)h->blob_used * 8)) return rc;
+    }
     std::atomic<int64_t> algo(0);
     const size_t chunk = 4096;
-    Staging* st = nullptr;
     if (stream_mode) {
-      // The record bytes go to the device as they are and are packed there (pack_kernels.hip).
-      // Straight out of the caller's memory when that is pinned and most of the run is wanted;
-      // else the wanted records are first gathered into pinned staging.
-      const uint64_t first = S.off[i0], extent = (uint64_t)S.off[i1 - 1] + S.rec_bytes[i1 - 1] - first;
-      if (extent > 0xffffffffull) return fail(h, BP_EINVAL, "%s: records spread over more than 4 GiB", who);
-      uint64_t wanted = 0;
-      for (int64_t i = i0; i < i1; i++) wanted += S.rec_bytes[i];
-      const bool direct = pinned_src && wanted * 4 >= extent * 3;
-      if (int rc = acquire_stage(h, &st, true, direct ? 0 : (size_t)wanted)) return rc;
-      const uint64_t shipped = direct ? extent : wanted;
-      if (int rc = ensure(h, h->d_raw, (size_t)shipped + 64, 0)) return rc;
-      if (int rc = ensure(h, h->d_pack, ns * sizeof(PackItem), 0)) return rc;
       const auto t_pack = std::chrono::steady_clock::now();
-      if (direct) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_raw.p, S.raw + first, (size_t)extent, hipMemcpyHostToDevice, h->stream));
-        wait_for_copy = true;
-      } else {
-        gsrc.resize(ns);
-        uint64_t at = 0;
-        for (size_t k = 0; k < ns; k++) {
-          gsrc[k] = (uint32_t)at;
-          at += S.rec_bytes[i0 + (int64_t)k];
-        }
-      }
       parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
         int64_t local = 0;
         for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
           const int64_t i = i0 + (int64_t)k;
           PackItem& it = st->items[k];
-          it.src = direct ? (uint32_t)(S.off[i] - first) : gsrc[k];
-          if (!direct) memcpy(st->raw + gsrc[k], S.raw + S.off[i], S.rec_bytes[i]);
+          it.src = direct ? (uint32_t)(S.off[i] - raw_first) : gsrc[k];
           it.blob = blob_base + (uint32_t)(boff[k] / 8);
           it.qdelta = (uint16_t)((qoff[k] - boff[k]) / 8);
           it.span = (uint16_t)std::min<int32_t>(spans[k], 0xffff);
@@ -990,8 +1049,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
         algo.fetch_add(local);
       });
       h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
-      if (!direct)
-        HIP_TRY(h, hipMemcpyAsync(h->d_raw.p, st->raw, (size_t)wanted, hipMemcpyHostToDevice, h->stream));
+      h->prof[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
       HIP_TRY(h, hipMemcpyAsync(h->d_pack.p, st->items, ns * sizeof(PackItem), hipMemcpyHostToDevice, h->stream));
       launch_pack((const uint8_t*)h->d_raw.p, (const PackItem*)h->d_pack.p, (int64_t)ns, (ReadCore*)h->d_cores.p + h->n_reads,
                   (uint8_t*)h->d_blob.p, h->stream);
@@ -1052,8 +1110,11 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
     h->blob_used += bytes / 8;
     i0 = i1;
   }
-  // the caller's memory is the caller's again when the call returns
-  if (wait_for_copy) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (wait_for_copy) {
+    wait_for_copy = false;
+    ProfTimer pt(&h->prof[6]);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
   poison.armed = false;
   return BP_OK;
 }
@@ -1084,9 +1145,10 @@ int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32
   h->x_ref.resize(N); h->x_pos.resize(N); h->x_mref.resize(N); h->x_mpos.resize(N);
   h->x_flags.resize(N); h->x_mapq.resize(N); h->x_lname.resize(N);
   h->x_ncig.resize(N); h->x_lseq.resize(N); h->x_bytes.resize(N);
+  h->x_span.resize(N); h->x_cfacts.resize(N);
   std::atomic<int64_t> bad(-1);
   const auto t0 = std::chrono::steady_clock::now();
-  const size_t chunk = 8192;
+  const size_t chunk = 2048;
   parallel_for((N + chunk - 1) / chunk, pack_threads(), [&](size_t c) {
     for (size_t k = c * chunk; k < std::min(N, (c + 1) * chunk); k++) {
       const uint64_t at = rec_off[k];
@@ -1109,6 +1171,10 @@ int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32
           h->x_mref[k] = (int32_t)w[6];
           h->x_mpos[k] = (int32_t)w[7];
           h->x_bytes[k] = 4 + block_size;
+          // the CIGAR lies right behind the name: its span now, while the record's lines are here
+          bool simp = false, has_bad = false;
+          h->x_span[k] = cigar_span(bam + at + 36 + l_name, n_cigar, &simp, &has_bad);
+          h->x_cfacts[k] = (uint8_t)((simp ? 1 : 0) | (has_bad ? 2 : 0));
         }
       }
       if (!ok) {
@@ -1119,6 +1185,7 @@ int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32
     }
   });
   h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  h->prof[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (bad.load() >= 0)
     return fail(h, BP_EINVAL, "bp_submit_bam: record %lld (offset %u) does not fit its block or the bytes given",
                 (long long)bad.load(), rec_off[bad.load()]);
@@ -1136,6 +1203,8 @@ int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32
   S.off = rec_off;
   S.l_name = h->x_lname.data();
   S.rec_bytes = h->x_bytes.data();
+  S.span = h->x_span.data();
+  S.cig_facts = h->x_cfacts.data();
   return submit_records(h, S, "bp_submit_bam");
 }
 
@@ -1650,6 +1719,12 @@ const char* bp_last_error(const bp_handle* h) { return h ? h->err.c_str() : g_la
 
 void bp_destroy(bp_handle* h) {
   if (!h) return;
+  if (const char* e = getenv("BP_PROFILE"); e && *e && *e != '0')
+    fprintf(stderr,
+            "bp profile (submit, s): extract %.3f layout %.3f scan-parallel %.3f scan-serial %.3f items %.3f "
+            "ensure %.3f copy-wait %.3f total %.3f; %lld records\n",
+            h->prof[0], h->prof[1], h->prof[2], h->prof[3], h->prof[4], h->prof[5], h->prof[6], h->prof[7],
+            (long long)h->n_reads);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->d_raw, &h->d_pack, &h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_tile_lo, &h->d_pr_feat, &h->d_seq8, &h->d_refname, &h->d_txt_len, &h->d_txt_tile, &h->d_txt_out, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,

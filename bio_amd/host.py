@@ -119,6 +119,18 @@ def bam_scan(path):
     return a.value, b.value, c.value, d.value
 
 
+def bam_scan_chunks(path):
+    """-> (n_records, n_chunks, hash record by record, hash chunk by chunk, sorted, fields_ok,
+    n_rewalked): the driver's reader run both ways over one file"""
+    lib = _abi.load()
+    n, nc, h1, h2, srt, ok, e = C.c_int64(), C.c_int64(), C.c_uint64(), C.c_uint64(), C.c_int32(), C.c_int32(), _err()
+    rw = C.c_int64()
+    if lib.bio_bam_scan_chunks(path.encode(), C.byref(n), C.byref(nc), C.byref(h1), C.byref(h2), C.byref(srt),
+                               C.byref(ok), C.byref(rw), e, len(e)):
+        raise ValueError(e.value.decode())
+    return n.value, nc.value, h1.value, h2.value, bool(srt.value), bool(ok.value), rw.value
+
+
 def bam_seek_scan(bam, index, ref_id, pos):
     """-> (found, first_ref, first_pos, n_skipped, n_at_or_after): the driver's index lookup and
     seek, then a read to the end of the file"""

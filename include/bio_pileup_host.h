@@ -83,6 +83,15 @@ int64_t bio_fasta_seq8(const char* path, const char* name, uint8_t* seq8, int64_
 int bio_bam_scan(const char* path, int64_t* n_records, int64_t* sum_l_seq, int64_t* sum_n_cigar,
                  int32_t* n_ref, char* err, size_t errlen);
 
+/* The same file read both ways the driver's reader offers - record by record, and a chunk of
+ * whole records at a time (the chain of block sizes walked in parallel stretches from guessed
+ * starts, every guess checked against the walk before it) - with an order-sensitive hash of
+ * the records' fixed fields each way; for tests: the hashes must agree.
+ * n_rewalked: stretches whose guessed start was wrong. */
+int bio_bam_scan_chunks(const char* path, int64_t* n_records, int64_t* n_chunks, uint64_t* hash_records,
+                        uint64_t* hash_chunks, int32_t* sorted, int32_t* fields_ok, int64_t* n_rewalked, char* err,
+                        size_t errlen);
+
 /* Index lookup + seek as the driver does them (bamIterator.reset, bamprovider.go:286-348;
  * .gbai: encoding/bam/gindex.go:35-121; .bai: SAM specification 5.2): loads index_path
  * (.bai or .gbai by suffix), asks for (ref_id, pos), seeks there and reads to the end of the

@@ -276,8 +276,8 @@ def test_job_cuts_with_halo_change_nothing(tmp_path, stitch, monkeypatch):
         monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(span))
         host.pileup(c.bam, c.fa, "basestrand-tsv", str(tmp_path / "cut"), o)
         assert c.read("cut.basestrand.tsv") == want, span
-    # and many small submits (each handed to the submitting thread while reading goes on)
-    monkeypatch.setenv("BIO_PILEUP_SUBMIT_RECORDS", "97")
+    # and many small chunks of the stream (each handed to the submitting thread while reading goes on)
+    monkeypatch.setenv("BIO_PILEUP_BATCH_BLOCKS", "1")
     for span in (700, 1 << 26):
         monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(span))
         host.pileup(c.bam, c.fa, "basestrand-tsv", str(tmp_path / "sub"), o)
@@ -371,7 +371,8 @@ def test_index_seeks_change_nothing(tmp_path):
     plain = str(tmp_path / "plain.bam")
     bamio.write_bam(plain, ref_names, ref_lens, batch)
     exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
-    env = dict(os.environ, BIO_PILEUP_STATS="1")
+    # (the whole file is less than one 16 MiB chunk of the reader: small chunks, so that there is something to skip)
+    env = dict(os.environ, BIO_PILEUP_STATS="1", BIO_PILEUP_BATCH_BLOCKS="2")
 
     def run(bam, tag, *extra):
         r = subprocess.run([exe, *extra, "-format", "basestrand-tsv", "-mapq", "0", "-out", str(tmp_path / tag), bam, fa],

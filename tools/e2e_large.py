@@ -44,12 +44,12 @@ n = rb.n
 sb.close()
 del rb
 exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
-env = dict(os.environ, BIO_PILEUP_STATS="1")
+env = dict(os.environ, BIO_PILEUP_STATS="1", BP_PROFILE="1")
 t0 = time.time()
 r = subprocess.run([exe, "-bed", bed, "-format", fmt, *extra, "-out", os.path.join(d, "o"), bam, fa],
                    capture_output=True, text=True, env=env)
 wall = time.time() - t0
-print(r.stderr.strip()[-600:], flush=True)
+print(r.stderr.strip()[-2600:], flush=True)
 outs = [p for p in os.listdir(d) if p.startswith("o.")]
 size = sum(os.path.getsize(os.path.join(d, p)) for p in outs)
 print(f"bio-pileup -bed all -format {fmt} {' '.join(extra)}: rc {r.returncode}, {wall:.1f} s wall, "

@@ -135,6 +135,99 @@ def committed_traffic(cfg, kernel):
     return None, None
 
 
+def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
+    """The whole run the reference's users see, for the same records: BAM (BGZF) + FASTA + BED ->
+    bio-pileup -> basestrand TSV on disk, process start to files closed, as aligned bases per
+    second; and beside it the CPU side of the same thing on a bounded sample: BAM -> records
+    (oracle/bam_decode.c, zlib, one thread) -> rows (oracle/pileup_oracle.c), without rendering."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from bio_amd import bamio, host
+    d = tempfile.mkdtemp(prefix="bp_e2e_", dir=os.environ.get("E2E_TMP", "/tmp"))
+    try:
+        t0 = time.time()
+        bam = os.path.join(d, "in.bam")
+        host.bam_write(bam, ["chr1"], [L], rb, level=1, threads=16)
+        rng = np.random.default_rng(1)
+        fa = os.path.join(d, "ref.fa")
+        seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
+        with open(fa, "wb") as f:
+            f.write(b">chr1\n")
+            lines = seq[: L // 60 * 60].reshape(-1, 60)
+            out = np.empty((lines.shape[0], 61), np.uint8)
+            out[:, :60] = lines
+            out[:, 60] = 10
+            f.write(out.tobytes())
+            if L % 60:
+                f.write(seq[L // 60 * 60:].tobytes() + b"\n")
+        del out, lines
+        bedp = os.path.join(d, "all.bed")
+        bamio.write_bed(bedp, [(0, 0, L)], ["chr1"])
+        make_s = time.time() - t0
+        flags = ["-bed", bedp, "-format", "basestrand-tsv"]
+        if o.MinBaseQual:
+            flags += ["-min-base-qual", str(o.MinBaseQual)]
+        if o.Clip:
+            flags += ["-clip", str(o.Clip)]
+        if o.Stitch:
+            flags += ["-stitch"]
+        exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
+        t0 = time.time()
+        r = subprocess.run([exe, *flags, "-out", os.path.join(d, "o"), bam, fa], capture_output=True, text=True,
+                           env=dict(os.environ, BIO_PILEUP_STATS="1"))
+        wall = time.time() - t0
+        if r.returncode != 0:
+            raise SystemExit("e2e: bio-pileup failed: " + r.stderr[-500:])
+        outp = os.path.join(d, "o.basestrand.tsv")
+        out_bytes = os.path.getsize(outp)
+        # the file says what the device rows say (first 20,000 positions)
+        n_chk = min(20000, L)
+        _, _, dv = job.rows(0, n_chk)
+        with open(outp, "rb") as f:
+            head = f.read(64 * n_chk).split(b"\n")[1:n_chk + 1]
+        for i, ln in enumerate(head):
+            fld = ln.split(b"\t")
+            if int(fld[1]) != i + 1 or [int(x) for x in fld[3:11]] != dv[i][1:9].tolist() or fld[2] != bytes(seq[i:i + 1]):
+                raise SystemExit(f"e2e: line {i + 2} of the output differs from the device rows")
+        m = re.search(r"read_s=([0-9.]+).*waiting for inflated blocks ([0-9.]+).*total_s=([0-9.]+)", r.stderr)
+        blk = {"value": round(B / wall / 1e9, 3), "unit": "Gbase/s", "wall_s": round(wall, 2),
+               "what": f"bio-pileup {' '.join(x for x in flags if not x.startswith('/'))}: BAM ({os.path.getsize(bam) / 1e9:.2f} GB, "
+                       f"BGZF level 1, {rb.n} records) + FASTA + BED -> basestrand.tsv ({out_bytes / 1e9:.2f} GB) on local disk, "
+                       f"process start to files closed; inflate on the host (16 threads), records found on the host, "
+                       f"packed on the device (bp_submit_bam), text rendered on the device",
+               "driver_stats": {"read_s": float(m.group(1)), "waiting_for_inflate_s": float(m.group(2)),
+                                "total_s": float(m.group(3))} if m else None,
+               "inputs_made_in_s": round(make_s, 1)}
+        for pth in (outp, bam):
+            os.remove(pth)
+        if with_cpu:
+            import oracle_lib as O
+            sample_bp = int(min(cpu_sample_mb * 1e6, L))
+            hi = int(np.searchsorted(rb.pos, sample_bp + (1200 if o.Stitch else 0), "left"))
+            sbam = os.path.join(d, "sample.bam")
+            host.bam_write(sbam, ["chr1"], [L], rb.slice(0, hi), level=1, threads=16)
+            oopts = O.make_opts(clip=o.Clip, mapq=o.Mapq, min_base_qual=o.MinBaseQual, stitch=int(o.Stitch))
+            tc = time.perf_counter()
+            srb, _ = O.bam_decode(sbam)
+            dec_s = time.perf_counter() - tc
+            _, _, wv = O.pileup(oopts, [L], {0: [[0, sample_bp]]}, srb, parallelism=1)
+            cpu_s = time.perf_counter() - tc
+            n_cmp = sample_bp - 1200
+            _, _, dv = job.rows(0, n_cmp)
+            if not (dv == wv[:n_cmp]).all():
+                raise SystemExit("e2e: device rows differ from the CPU oracle's rows from the decoded sample BAM")
+            cpu_B = kept_aligned_bases(srb, opts_kw, [[0, sample_bp]])
+            blk["cpu"] = {"value": round(cpu_B / cpu_s / 1e9, 4), "unit": "Gbase/s", "cores": 1, "kind": "port",
+                          "sample": f"first {sample_bp / 1e6:.0f} Mb ({hi} records, {os.path.getsize(sbam) / 1e9:.2f} GB BAM): "
+                                    f"BGZF inflate + record decode (oracle/bam_decode.c, zlib) {dec_s:.1f} s, then rows "
+                                    f"(oracle/pileup_oracle.c) - {cpu_s:.1f} s in all, 1 thread, no text output"}
+        return blk
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def c3_share(rank, world):
     """Position ranges of rank `rank` when the 24 contigs are cut into `world` runs of equal size."""
     from bio_amd import partition
@@ -153,6 +246,9 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=None,
                     help="genomic megabases of the workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end block (BAM + FASTA -> files through bio-pileup; c2* configs at N=1)")
+    ap.add_argument("--e2e-cpu-sample-mb", type=float, default=20.0)
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     cname = args.config
@@ -395,6 +491,10 @@ def main():
             cpu["all_cores"] = {"value": round(mt_B / mt_s / 1e9, 4), "unit": "Gbase/s", "cores": T,
                                 "sample": f"the whole workload as {T} position ranges, one thread each, in {mt_s:.1f} s"}
 
+    e2e = None
+    if rank == 0 and pworld == 1 and not args.no_e2e and cname in ("c2", "c2q", "c2c", "c2s") and not emulate:
+        e2e = e2e_block(rb, L, B, o, opts_kw, job, args.e2e_cpu_sample_mb, not args.no_cpu_baseline)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         k_ms = float(np.mean(kernel_ms))
@@ -449,6 +549,7 @@ def main():
                                 "unit": "G ds_add_u32 lanes/s", "frac": round(B / (k_ms * 1e-3) / 1e9 / LDS_ATOMIC_PEAK_G, 4)},
             },
             "cpu_baseline": cpu,
+            "e2e": e2e,
             "setup": {"generate_s": round(gen_s, 1), "pack_and_h2d_s": round(submit_s, 2), "finish_s": round(finish_s, 3),
                       # inside bp_submit: the serial pass in record order (order check, errors, mate pairing
                       # in stitch mode) and the passes on all packing threads (spans, filters, hashes, packing)

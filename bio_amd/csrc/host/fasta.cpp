@@ -3,6 +3,7 @@
 // pileup/common.go:169-225).
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "bio_host.h"
@@ -29,38 +30,60 @@ std::string LoadFaSeq8(const std::string& path, Fasta* out) {
 
   out->names.clear();
   out->seqs.clear();
-  std::string seq_name, seq_buf, line;
-  std::vector<char> buf(1 << 20);
-  bool eof = false;
-  while (!eof) {
-    line.clear();
-    for (;;) {
-      if (!gzgets(f, buf.data(), (int)buf.size())) { eof = true; break; }
-      line += buf.data();
-      if (!line.empty() && line.back() == '\n') break;
-    }
-    if (eof && line.empty()) break;
-    if (!line.empty() && line.back() == '\n') line.pop_back();
-    if (!line.empty() && line.back() == '\r') line.pop_back();  // bufio.ScanLines drops one trailing \r
-    if (line.empty()) continue;
-    if (line[0] == '>') {
+  // The file in 8 MiB blocks, lines found with memchr: a chromosome is millions of 60-byte lines.
+  std::string seq_name, seq_buf, carry;
+  std::vector<char> buf(8 << 20);
+  std::string bad;
+  auto take_line = [&](const char* p, size_t n) {  // one line without its '\n'
+    if (n && p[n - 1] == '\r') n--;  // bufio.ScanLines drops one trailing \r
+    if (n == 0) return;
+    if (p[0] == '>') {
       if (!seq_buf.empty()) {
-        if (seq_name.empty()) { gzclose(f); return "malformed FASTA file"; }
+        if (seq_name.empty()) { bad = "malformed FASTA file"; return; }
         out->names.push_back(seq_name);
-        out->seqs.push_back(seq_buf);
+        seq_buf.shrink_to_fit();
+        out->seqs.push_back(std::move(seq_buf));
         seq_buf.clear();
       }
-      size_t sp = line.find(' ', 1);
-      seq_name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+      const char* sp = (const char*)memchr(p + 1, ' ', n - 1);
+      seq_name.assign(p + 1, sp ? (size_t)(sp - p - 1) : n - 1);
     } else {
-      size_t o = seq_buf.size();
-      seq_buf.resize(o + line.size());
-      for (size_t i = 0; i < line.size(); i++) seq_buf[o + i] = (char)tab[(uint8_t)line[i]];
+      const size_t o = seq_buf.size();
+      if (seq_buf.capacity() < o + n) seq_buf.reserve(std::max<size_t>(2 * seq_buf.capacity(), (size_t)64 << 20));
+      seq_buf.resize(o + n);
+      char* d = &seq_buf[o];
+      for (size_t i = 0; i < n; i++) d[i] = (char)tab[(uint8_t)p[i]];
     }
+  };
+  for (;;) {
+    const int got = gzread(f, buf.data(), (unsigned)buf.size());
+    if (got < 0) { gzclose(f); return "read " + path + ": corrupt compressed data"; }
+    if (got == 0) break;
+    const char* p = buf.data();
+    const char* const end = p + got;
+    while (p < end && bad.empty()) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+      if (!nl) {
+        carry.append(p, (size_t)(end - p));
+        break;
+      }
+      if (!carry.empty()) {
+        carry.append(p, (size_t)(nl - p));
+        take_line(carry.data(), carry.size());
+        carry.clear();
+      } else {
+        take_line(p, (size_t)(nl - p));
+      }
+      p = nl + 1;
+    }
+    if (!bad.empty()) { gzclose(f); return bad; }
   }
+  if (!carry.empty()) take_line(carry.data(), carry.size());  // last line without a newline
   gzclose(f);
+  if (!bad.empty()) return bad;
   out->names.push_back(seq_name);
-  out->seqs.push_back(seq_buf);
+  seq_buf.shrink_to_fit();
+  out->seqs.push_back(std::move(seq_buf));
   return "";
 }
 

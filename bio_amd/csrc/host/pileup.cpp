@@ -543,19 +543,24 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (!err.empty()) return err;
   }
 
-  // 3. reference sequences (pileup.go:1107-1114)
+  // 3. reference sequences (pileup.go:1107-1114).  Loading them is a good part of a second for a
+  //    human chromosome and nothing needs them before the first job opens: they are read on a
+  //    thread of their own while the run is set up and the first chunk of the BAM is inflated.
   Fasta fa;
-  {
-    std::string err = LoadFaSeq8(fapath, &fa);
-    if (!err.empty()) return err;
-  }
-  std::vector<const std::string*> ref_seqs;
-  std::string warnings;
-  {
-    std::string err = FaToStringSlice(fa, hd, &ref_seqs, &warnings);
-    if (!err.empty()) return err;
-    if (!warnings.empty()) fputs(warnings.c_str(), stderr);
-  }
+  std::vector<const std::string*> ref_seqs(hd.ref_names.size(), nullptr);
+  if (access(fapath.c_str(), R_OK) != 0) return "open " + fapath + ": no such file or directory";
+  std::future<std::string> fa_load = std::async(std::launch::async, [&fa, &fapath] { return LoadFaSeq8(fapath, &fa); });
+  bool fa_done = false;
+  std::string fa_err;
+  auto need_fa = [&]() -> const std::string& {
+    if (fa_done) return fa_err;
+    fa_done = true;
+    fa_err = fa_load.get();
+    std::string warnings;
+    if (fa_err.empty()) fa_err = FaToStringSlice(fa, hd, &ref_seqs, &warnings);
+    if (fa_err.empty() && !warnings.empty()) fputs(warnings.c_str(), stderr);
+    return fa_err;
+  };
 
   // 4. pileupSNPMain set-up (pileup.go:812-835, :887-888, :944-966)
   const bool tsv_format = fmt == kTsv || fmt == kTsvBgz;
@@ -651,7 +656,8 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   for (size_t k = 0; k < drv.n_closers(); k++) closers.emplace_back(new Closer(&drv, &gate));
   Submitter submitter(&drv);
   auto open_job = [&]() -> std::string {
-    std::string e = drv.OpenJob(jobs[ji]);
+    std::string e = need_fa();
+    if (e.empty()) e = drv.OpenJob(jobs[ji]);
     open = e.empty();
     // what the job was given while the ones before it were open
     for (Piece& p : pend[0])
@@ -845,6 +851,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   }
   for (auto& v : sel) v.clear();
   ck = BamReader::Chunk();
+  if (err.empty()) err = need_fa();
   // jobs after the last record still emit their (zero) rows (flushEmptyContigs,
   // pileup_support.go:112-123)
   while (err.empty() && ji < jobs.size()) {

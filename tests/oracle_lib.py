@@ -203,3 +203,47 @@ def pileup_per_read(opts, ref_len, bed, batch, shards=None, n_shards=None, paral
         raise OracleError(err.value.decode())
     n = n_rows.value
     return out_ref[:n], out_pos[:n], out_vals[:n], out_off[:4 * n + 1], out_feat[:n_feat.value]
+
+
+class orc_bam(C.Structure):
+    """oracle/bam_decode.c"""
+    _fields_ = [("n", C.c_int64), ("n_ref", C.c_int32)] + \
+               [(k, C.POINTER(C.c_int32)) for k in ("ref_id", "pos", "mate_ref_id", "mate_pos")] + \
+               [("flags", C.POINTER(C.c_uint16)), ("mapq", C.POINTER(C.c_uint8)),
+                ("n_cigar", C.POINTER(C.c_uint32)), ("l_seq", C.POINTER(C.c_uint32))] + \
+               [(k, C.POINTER(C.c_uint64)) for k in ("cigar_off", "seq_off", "qual_off", "name_off")] + \
+               [("cigar", C.POINTER(C.c_uint32)), ("seq", C.POINTER(C.c_uint8)), ("qual", C.POINTER(C.c_uint8)),
+                ("name", C.POINTER(C.c_uint8))] + \
+               [(k, C.c_uint64) for k in ("n_cigar_ops", "n_seq_bytes", "n_qual_bytes", "n_name_bytes")]
+
+
+def bam_decode(path):
+    """BAM file -> RecordBatch with the oracle's own single-threaded BGZF + record decoder
+    (oracle/bam_decode.c); returns (batch, n_ref)."""
+    from bio_amd import records as R
+    lib_path = os.path.join(ORACLE_DIR, "_build", "libbamdecode.so")
+    if not os.path.exists(lib_path):
+        build()
+    lib = C.CDLL(lib_path)
+    lib.orc_bam_decode.argtypes = [C.c_char_p, C.POINTER(orc_bam), C.c_char_p, C.c_int]
+    lib.orc_bam_decode.restype = C.c_int
+    lib.orc_bam_free.argtypes = [C.POINTER(orc_bam)]
+    lib.orc_bam_free.restype = None
+    b = orc_bam()
+    err = C.create_string_buffer(256)
+    if lib.orc_bam_decode(path.encode(), C.byref(b), err, 256) != 0:
+        raise OracleError(err.value.decode())
+    n = int(b.n)
+
+    def arr(p, cnt):
+        return np.ctypeslib.as_array(p, shape=(max(int(cnt), 1),))[:int(cnt)].copy()
+    kw = {k: arr(getattr(b, k), n) for k in ("ref_id", "pos", "mate_ref_id", "mate_pos", "flags", "mapq", "n_cigar",
+                                              "l_seq", "cigar_off", "seq_off", "qual_off")}
+    kw["name_off"] = arr(b.name_off, n + 1)
+    kw["cigar"] = arr(b.cigar, b.n_cigar_ops)
+    kw["seq"] = arr(b.seq, b.n_seq_bytes)
+    kw["qual"] = arr(b.qual, b.n_qual_bytes)
+    kw["name"] = arr(b.name, b.n_name_bytes)
+    n_ref = int(b.n_ref)
+    lib.orc_bam_free(C.byref(b))
+    return R.RecordBatch(**kw), n_ref

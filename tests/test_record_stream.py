@@ -39,3 +39,23 @@ def test_record_stream_is_the_body_of_the_bam_file(tmp_path):
     st2, off2 = bamio.record_stream(rb, aux_bytes=7)
     assert st2.size == st.size + 7 * rb.n
     assert bytes(st2[int(off2[1]) - 7:int(off2[1])]) == b"XXZaaa\0"
+
+
+def test_oracle_bam_decoder_reads_back_what_was_written(tmp_path):
+    """oracle/bam_decode.c (the CPU baseline's BAM -> records step) against the records a BAM was
+    written from, for the Python writer and the product's writer"""
+    import oracle_lib as O
+    from bio_amd import host
+    rng = random.Random(9)
+    rb = R.from_records(random_records(rng, 400, n_ref=2))
+    for how in ("python", "product"):
+        path = str(tmp_path / f"{how}.bam")
+        if how == "python":
+            bamio.write_bam(path, ["a", "b"], [3000, 2500], rb)
+        else:
+            host.bam_write(path, ["a", "b"], [3000, 2500], rb, level=1, threads=2)
+        got, n_ref = O.bam_decode(path)
+        assert n_ref == 2 and got.n == rb.n
+        for k in ("ref_id", "pos", "mate_ref_id", "mate_pos", "flags", "mapq", "n_cigar", "l_seq", "cigar", "seq", "qual"):
+            assert (getattr(got, k) == getattr(rb, k)).all(), (how, k)
+        assert bytes(got.name) == bytes(rb.name) and (got.name_off == rb.name_off).all()

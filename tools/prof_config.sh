@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 python3 -u $R/bench.py --config $cfg "$@" > $out/bench.log 2>&1 || { echo bench failed; tail -5 $out/bench.log; exit 1; }
 tail -1 $out/bench.log > $R/gpurun_out/${tag}_bench_$cfg.json
 cut -c1-400 $R/gpurun_out/${tag}_bench_$cfg.json
-ARGS="--config $cfg --steps 5 --warmup 1 --no-cpu-baseline $@"
+ARGS="--config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-e2e $@"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py $ARGS > $out/trace.log 2>&1 || { echo trace failed; tail -5 $out/trace.log; exit 1; }
 i=0
 for pmc in "FETCH_SIZE" \

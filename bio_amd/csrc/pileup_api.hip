@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -108,7 +109,7 @@ struct StoredRead {
   int32_t next;      // chain / free list
 };
 
-struct FirstReadTable {
+struct alignas(128) FirstReadTable {  // (one per thread in scan_slice: no two on a cache line)
   std::vector<int32_t> head;   // [nCirc] chain heads, -1 = empty
   std::vector<StoredRead> ents;
   std::vector<char> names;
@@ -212,6 +213,22 @@ struct FirstReadTable {
   }
 };
 
+constexpr int kMatePartitions = 16;
+
+struct PairItem {  // a read that can pair, as its partition's pass over the firstread table needs it
+  uint64_t hash;
+  const uint8_t* name;
+  uint32_t k, name_len;  // index in the slice
+  int32_t ref, pos, mate_pos;
+  uint32_t rev;          // MATE_PAIR_REV if a pair this read completes counts on the reverse strand
+  MateEntry self;
+};
+
+struct PairOut {  // a pair found by scan_slice: record indices and what the mate table gets for each
+  int64_t second, first;
+  MateEntry of_second, of_first;
+};
+
 inline uint64_t name_hash(const uint8_t* p, size_t n) {
   // 8 bytes at a time, multiply-mix (the hash only has to spread names; equality is checked on the bytes)
   uint64_t h = 0x9e3779b97f4a7c15ull ^ (n * 0xff51afd7ed558ccdull);
@@ -267,7 +284,10 @@ struct bp_handle {
   // stitch: host mate table
   std::vector<MateEntry> mate;                        // per record
   bool mate_dirty = true;                             // changed since it was last copied to the device
-  FirstReadTable stored;
+  FirstReadTable stored[kMatePartitions];  // by name hash (scan_slice)
+  std::vector<PairOut> pair_out[kMatePartitions];
+  std::vector<PairItem> pair_items;   // of the slice, chunk by chunk, each chunk's in partition order
+  std::vector<uint32_t> pair_start;   // [chunk][partition] -> first item; kMatePartitions + 1 entries a chunk
   std::vector<uint8_t> scan_cls;
   // bp_submit_bam: fixed fields of the call's records, pulled out of the stream
   std::vector<int32_t> x_ref, x_pos, x_mref, x_mpos;
@@ -572,11 +592,18 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
   std::vector<uint8_t>& cls = h->scan_cls;      // (scratch kept with the handle between slices)
   std::vector<uint64_t>& hashes = h->scan_hash;
   cls.assign(ns, 0);
-  if (o.stitch) hashes.resize(ns);
+  const size_t chunk = 8192;
+  const size_t n_chunks = (ns + chunk - 1) / chunk;
+  if (o.stitch) {
+    hashes.resize(ns);
+    if (h->pair_items.size() < ns) h->pair_items.resize(ns);
+    h->pair_start.assign(n_chunks * (kMatePartitions + 1), 0);
+  }
   const int32_t nref = (int32_t)h->ref_len.size();
   const auto t_par = std::chrono::steady_clock::now();
-  const size_t chunk = 8192;
-  parallel_for((ns + chunk - 1) / chunk, nthreads, [&](size_t c) {
+  parallel_for(n_chunks, nthreads, [&](size_t c) {
+    thread_local std::vector<PairItem> found;  // the chunk's reads that can pair, in record order
+    found.clear();
     for (size_t k = c * chunk; k < std::min(ns, (c + 1) * chunk); k++) {
       const int64_t i = i0 + (int64_t)k;
       const uint32_t n_cigar = S.n_cigar[i];
@@ -619,11 +646,39 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
           const int32_t mate_pos = S.mate_pos[i];
           if (!(strand == 0 || mate_pos >= map_end || (int64_t)mate_pos + o.max_read_span <= (int64_t)pos)) {
             f |= SC_PAIRABLE;
-            hashes[k] = name_hash(S.name(i), (size_t)S.name_len(i));
+            PairItem it;
+            it.name = S.name(i);
+            it.name_len = S.name_len(i);
+            it.hash = hashes[k] = name_hash(it.name, (size_t)it.name_len);
+            it.k = (uint32_t)k;
+            it.ref = ref;
+            it.pos = pos;
+            it.mate_pos = mate_pos;
+            it.rev = (!o.ignore_strand && strand == 2) ? MATE_PAIR_REV : 0u;
+            it.self.x = (simp ? MATE_SIMPLE : 0u) | MATE_HAS;
+            it.self.blob = blob_base + (uint32_t)(boff[k] / 8);
+            it.self.span_lseq = (uint32_t)span | ((uint32_t)S.l_seq[i] << 16);
+            it.self.ncig_qdelta = n_cigar | ((uint32_t)((qoff[k] - boff[k]) / 8) << 16);
+            found.push_back(it);
           }
         }
       }
       cls[k] = f;
+    }
+    if (o.stitch) {
+      // into the chunk's stretch of pair_items, by partition, record order kept inside each
+      uint32_t* start = h->pair_start.data() + c * (kMatePartitions + 1);
+      uint32_t count[kMatePartitions] = {};
+      for (const PairItem& it : found) count[(it.hash >> 58) % kMatePartitions]++;
+      uint32_t at = (uint32_t)(c * chunk);
+      for (int p = 0; p < kMatePartitions; p++) {
+        start[p] = at;
+        at += count[p];
+      }
+      start[kMatePartitions] = at;
+      uint32_t fill[kMatePartitions];
+      memcpy(fill, start, sizeof fill);
+      for (const PairItem& it : found) h->pair_items[fill[(it.hash >> 58) % kMatePartitions]++] = it;
     }
   });
   const auto t_ser = std::chrono::steady_clock::now();
@@ -637,7 +692,8 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
       h->scan_s += d;
       h->prof[3] += d;
     }
-  } timer{h, t_ser};
+  };
+  std::unique_ptr<Timer> timer(new Timer{h, t_ser});
 
   for (size_t k = 0; k < ns; k++) {
     const int64_t i = i0 + (int64_t)k;
@@ -689,40 +745,70 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
                       ref_label(h, ref, tmp, sizeof tmp), pos);
       }
     }
-    if (!(f & SC_PAIRABLE)) continue;
-    // firstreadSNPTable.addOrRemove (firstread.go:176-204)
-    FirstReadTable& T = h->stored;
-    T.advance(ref, pos);
-    const int32_t mate_pos = S.mate_pos[i];
-    const uint8_t* nm = S.name(i);
-    const uint32_t nlen = S.name_len(i);
-    const int strand = strand_of(ref, S.mate_ref_id[i], S.flags[i]);
-    StoredRead me{};
-    me.hash = hashes[k];
-    me.key_pos = mate_pos;
-    me.pos = pos;
-    me.idx = gidx;
-    me.name_len = nlen;
-    me.self.x = (simple[k] ? MATE_SIMPLE : 0u) | MATE_HAS;
-    me.self.blob = blob_base + (uint32_t)(boff[k] / 8);
-    me.self.span_lseq = (uint32_t)span | ((uint32_t)S.l_seq[i] << 16);
-    me.self.ncig_qdelta = S.n_cigar[i] | ((uint32_t)((qoff[k] - boff[k]) / 8) << 16);
-    if (pos >= mate_pos) {
-      StoredRead a;
-      if (T.try_remove(pos, mate_pos, me.hash, nm, nlen, &a)) {
-        // the pair is counted on the strand of the read that found its mate (pileup.go:799-802)
-        const uint32_t rev = (!o.ignore_strand && strand == 2) ? MATE_PAIR_REV : 0u;
-        MateEntry eb = a.self, ea = me.self;
-        eb.x |= ((uint32_t)(a.pos - pos) & 0x1ffffu) | MATE_SECOND | rev;
-        ea.x |= ((uint32_t)(pos - a.pos) & 0x1ffffu) | rev;
-        h->mate[(size_t)gidx] = eb;
-        h->mate[(size_t)a.idx] = ea;
-        continue;
-      }
-      if (pos != mate_pos) continue;  // missing mate: processed alone
-    }
-    T.add(me, nm);
   }
+  timer.reset();
+  if (!o.stitch) return 0;
+  // firstreadSNPTable.addOrRemove (firstread.go:176-204) for the reads that can pair.  Two reads
+  // meet in the table only if they have the same name, so the table is kept as kMatePartitions
+  // tables by name hash, each worked by one thread over the slice's records in order: within a
+  // partition everything happens in the order one table would see it (so "the one stored first"
+  // still wins), and partitions never look at each other's reads.  Evictions are per table and lazy
+  // (a stored read whose mate would have had to start before the current position can never be
+  // taken again, whenever it is dropped).  The parallel pass above has listed each partition's reads
+  // with all that is needed of them (a partition that picked its reads out of the record columns
+  // would pull every cache line of every column: 16 threads x the whole slice); the pairs a partition
+  // finds are listed too and entered afterwards.
+  const auto t_pair = std::chrono::steady_clock::now();
+  parallel_for((size_t)kMatePartitions, nthreads, [&](size_t part) {
+    FirstReadTable& T = h->stored[part];
+    std::vector<PairOut>& out = h->pair_out[part];
+    out.clear();
+    for (size_t c = 0; c < n_chunks; c++) {
+      const uint32_t* start = h->pair_start.data() + c * (kMatePartitions + 1);
+      for (uint32_t x = start[part]; x < start[part + 1]; x++) {
+        const PairItem& it = h->pair_items[x];
+        const int64_t gidx = h->n_reads + (int64_t)it.k;
+        T.advance(it.ref, it.pos);
+        StoredRead me{};
+        me.hash = it.hash;
+        me.key_pos = it.mate_pos;
+        me.pos = it.pos;
+        me.idx = gidx;
+        me.name_len = it.name_len;
+        me.self = it.self;
+        if (it.pos >= it.mate_pos) {
+          StoredRead a;
+          if (T.try_remove(it.pos, it.mate_pos, it.hash, it.name, it.name_len, &a)) {
+            // the pair is counted on the strand of the read that found its mate (pileup.go:799-802)
+            MateEntry eb = a.self, ea = me.self;
+            eb.x |= ((uint32_t)(a.pos - it.pos) & 0x1ffffu) | MATE_SECOND | it.rev;
+            ea.x |= ((uint32_t)(it.pos - a.pos) & 0x1ffffu) | it.rev;
+            out.push_back({gidx, a.idx, eb, ea});
+            continue;
+          }
+          if (it.pos != it.mate_pos) continue;  // missing mate: processed alone
+        }
+        T.add(me, it.name);
+      }
+    }
+  });
+  // The entries go into the mate table by record range, not by partition: partitions work through
+  // the same records at the same time, and their pairs' entries lie side by side in the table
+  // (16 bytes each), so writing them from the partition threads has every cache line of the table
+  // bounce between cores.  Each list is in the order of the second read's index.
+  constexpr size_t kRanges = 16;
+  parallel_for(kRanges, nthreads, [&](size_t r) {
+    const int64_t lo = h->n_reads + (int64_t)(ns * r / kRanges), hi = h->n_reads + (int64_t)(ns * (r + 1) / kRanges);
+    for (int part = 0; part < kMatePartitions; part++) {
+      const std::vector<PairOut>& out = h->pair_out[part];
+      auto it = std::lower_bound(out.begin(), out.end(), lo, [](const PairOut& a, int64_t x) { return a.second < x; });
+      for (; it != out.end() && it->second < hi; ++it) {
+        h->mate[(size_t)it->second] = it->of_second;
+        h->mate[(size_t)it->first] = it->of_first;
+      }
+    }
+  });
+  h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pair).count();
   return 0;
 }
 
@@ -831,7 +917,7 @@ int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const 
   h->bed.resize((size_t)n_ref);
   h->ref_first.assign((size_t)n_ref + 1, 0);
   if (int rc = build_qthr(h)) { delete h; return rc; }
-  h->stored.init(opts->max_read_span);
+  for (FirstReadTable& t : h->stored) t.init(opts->max_read_span);
   auto bail = [&](const char* what, hipError_t e) {
     int rc = fail(nullptr, BP_EDEVICE, "%s: %s", what, hipGetErrorString(e));
     bp_destroy(h);
@@ -1373,7 +1459,7 @@ int bp_compute_static(bp_handle* h) {
 int bp_finish(bp_handle* h) {
   if (!h) return fail(h, BP_EINVAL, "bp_finish: null handle");
   h->finished = true;
-  h->stored.clear();
+  for (FirstReadTable& t : h->stored) t.clear();
   return bp_compute(h);
 }
 

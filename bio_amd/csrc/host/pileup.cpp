@@ -544,23 +544,21 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   }
 
   // 3. reference sequences (pileup.go:1107-1114).  Loading them is a good part of a second for a
-  //    human chromosome and nothing needs them before the first job opens: they are read on a
-  //    thread of their own while the run is set up and the first chunk of the BAM is inflated.
+  //    human chromosome, and so is bringing up the HIP runtime: the two run side by side.
   Fasta fa;
-  std::vector<const std::string*> ref_seqs(hd.ref_names.size(), nullptr);
+  std::vector<const std::string*> ref_seqs;
   if (access(fapath.c_str(), R_OK) != 0) return "open " + fapath + ": no such file or directory";
-  std::future<std::string> fa_load = std::async(std::launch::async, [&fa, &fapath] { return LoadFaSeq8(fapath, &fa); });
-  bool fa_done = false;
-  std::string fa_err;
-  auto need_fa = [&]() -> const std::string& {
-    if (fa_done) return fa_err;
-    fa_done = true;
-    fa_err = fa_load.get();
+  std::future<int> dev_init = std::async(std::launch::async, [&opts] { return bp_init(opts.Device); });
+  {
+    std::string err = LoadFaSeq8(fapath, &fa);
     std::string warnings;
-    if (fa_err.empty()) fa_err = FaToStringSlice(fa, hd, &ref_seqs, &warnings);
-    if (fa_err.empty() && !warnings.empty()) fputs(warnings.c_str(), stderr);
-    return fa_err;
-  };
+    if (err.empty()) err = FaToStringSlice(fa, hd, &ref_seqs, &warnings);
+    if (!err.empty()) {
+      (void)dev_init.get();
+      return err;
+    }
+    if (!warnings.empty()) fputs(warnings.c_str(), stderr);
+  }
 
   // 4. pileupSNPMain set-up (pileup.go:812-835, :887-888, :944-966)
   const bool tsv_format = fmt == kTsv || fmt == kTsvBgz;
@@ -575,7 +573,11 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   if (per_read && opts.Stitch)
     // the reference panics at the first pair it merges (pileup.go:422-443); refused up front
     return "stitched per-read features not yet supported";
-  if (bp_init(opts.Device) != BP_OK) return bp_last_error(nullptr);
+  if (dev_init.get() != BP_OK) {
+    // (the message is the initialising thread's: ask again on this one)
+    (void)bp_init(opts.Device);
+    return bp_last_error(nullptr);
+  }
   // -devices N | all: N logical devices, mapped round-robin onto the physical ones
   std::vector<int> devices;
   if (opts.Devices != 0) {
@@ -656,8 +658,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   for (size_t k = 0; k < drv.n_closers(); k++) closers.emplace_back(new Closer(&drv, &gate));
   Submitter submitter(&drv);
   auto open_job = [&]() -> std::string {
-    std::string e = need_fa();
-    if (e.empty()) e = drv.OpenJob(jobs[ji]);
+    std::string e = drv.OpenJob(jobs[ji]);
     open = e.empty();
     // what the job was given while the ones before it were open
     for (Piece& p : pend[0])
@@ -851,7 +852,6 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   }
   for (auto& v : sel) v.clear();
   ck = BamReader::Chunk();
-  if (err.empty()) err = need_fa();
   // jobs after the last record still emit their (zero) rows (flushEmptyContigs,
   // pileup_support.go:112-123)
   while (err.empty() && ji < jobs.size()) {

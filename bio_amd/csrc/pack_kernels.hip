@@ -37,7 +37,8 @@ __device__ __forceinline__ uint32_t ld_upto4(const uint8_t* p, uint32_t n) {
 
 __global__ __launch_bounds__(kPackBlock) void pack_records(const uint8_t* __restrict__ raw,
                                                            const PackItem* __restrict__ items, int64_t n,
-                                                           ReadCore* __restrict__ cores, uint8_t* __restrict__ blob) {
+                                                           ReadCore* __restrict__ cores, uint8_t* __restrict__ blob,
+                                                           int qpass, int min_base_qual, int clip) {
   const int64_t k = (int64_t)blockIdx.x * (kPackBlock / 64) + (threadIdx.x >> 6);
   if (k >= n) return;
   const uint32_t lane = threadIdx.x & 63u;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(kPackBlock) void pack_records(const uint8_t* __rest
   const uint32_t ncp = (n_cigar + 1) & ~1u;
   const uint32_t U = (l + 7) >> 3;  // blob_units()
   const uint32_t sb = (l + 1) >> 1;
-  const uint32_t base_dw = (ncp + U + 1) & ~1u;  // base_part_bytes() / 4: CIGAR + 4U base bytes, to whole 8-byte units
+  const uint32_t qp_dw = qpass ? (U + 3) >> 2 : 0u;       // pass bits, one per base, to a whole dword
+  const uint32_t base_dw = (ncp + U + qp_dw + 1) & ~1u;   // base_part_bytes() / 4, to whole 8-byte units
   uint32_t* const d = (uint32_t*)(blob + (size_t)it.blob * 8);
   for (uint32_t w = lane; w < base_dw; w += 64) {
     uint32_t v = 0;
@@ -75,6 +77,15 @@ __global__ __launch_bounds__(kPackBlock) void pack_records(const uint8_t* __rest
       const uint32_t b0 = 4 * (w - ncp);
       v = b0 < sb ? ld_upto4(seq + b0, sb - b0) : 0u;
       v = ((v & 0x0f0f0f0fu) << 4) | ((v >> 4) & 0x0f0f0f0fu);  // first base of a byte to the low nibble
+    } else if (w >= ncp + U && w - (ncp + U) < qp_dw) {
+      // bit b of the dword: base 32t + b passes the quality rule (clipQuals, then addBase's test)
+      const uint32_t b0 = 32 * (w - (ncp + U));
+      for (uint32_t b = 0; b < 32 && b0 + b < l; b++) {
+        const uint32_t i = b0 + b;
+        uint32_t q = qual[i];
+        if (2 * (uint32_t)clip >= l || i < (uint32_t)clip || i >= l - (uint32_t)clip) q = 2;
+        v |= (q >= (uint32_t)min_base_qual ? 1u : 0u) << b;
+      }
     }
     d[w] = v;
   }
@@ -87,12 +98,12 @@ __global__ __launch_bounds__(kPackBlock) void pack_records(const uint8_t* __rest
 
 }  // namespace
 
-void launch_pack(const uint8_t* raw, const PackItem* items, int64_t n, ReadCore* cores, uint8_t* blob,
-                 hipStream_t s) {
+void launch_pack(const uint8_t* raw, const PackItem* items, int64_t n, ReadCore* cores, uint8_t* blob, int qpass,
+                 int min_base_qual, int clip, hipStream_t s) {
   if (n <= 0) return;
   const int64_t per = kPackBlock / 64;
   hipLaunchKernelGGL(pack_records, dim3((unsigned)((n + per - 1) / per)), dim3(kPackBlock), 0, s, raw, items, n,
-                     cores, blob);
+                     cores, blob, qpass, min_base_qual, clip);
 }
 
 }  // namespace bp

@@ -41,8 +41,8 @@ void launch_tile_scan(const uint32_t* rows, uint32_t* off32, int64_t n, unsigned
 void launch_per_read(const KernelParams& P, PerReadParams Q, hipStream_t s);
 void launch_text(const TextParams& T, hipStream_t s);
 void launch_text_write(const TextParams& T, hipStream_t s);
-void launch_pack(const uint8_t* raw, const PackItem* items, int64_t n, ReadCore* cores, uint8_t* blob,
-                 hipStream_t s);
+void launch_pack(const uint8_t* raw, const PackItem* items, int64_t n, ReadCore* cores, uint8_t* blob, int qpass,
+                 int min_base_qual, int clip, hipStream_t s);
 }  // namespace bp
 
 using namespace bp;
@@ -255,6 +255,7 @@ struct bp_handle {
   std::vector<std::string> ref_name;
   std::vector<std::vector<int32_t>> bed;  // per reference endpoint arrays
   bool frozen = false;                    // BED fixed, windows built
+  bool qpass = false;                     // payloads carry one pass bit per base (pileup_device.h): every job but those in which every base passes
   bool finished = false;
   std::string err;
   // A bp_submit that failed part-way has already moved the order key, the per-reference record
@@ -908,6 +909,7 @@ int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const 
   if (int rc = bp_init(opts->device)) return rc;
   bp_handle* h = new bp_handle();
   h->o = *opts;
+  h->qpass = opts->stitch || opts->min_base_qual > 0;
   h->device = opts->device;
   h->ref_len.assign(ref_len, ref_len + n_ref);
   h->ref_name.resize((size_t)n_ref);
@@ -939,7 +941,7 @@ int bp_reserve(bp_handle* h, int64_t n_records, int64_t payload_bytes) {
   if (!h || n_records < 0 || payload_bytes < 0) return fail(h, BP_EINVAL, "bp_reserve: bad argument");
   HIP_TRY(h, hipSetDevice(h->device));
   // payload grows by padding: cigar to even count, qual/seq to whole 8-base units
-  size_t blob = (size_t)payload_bytes + (size_t)n_records * 16 + 4096;
+  size_t blob = (size_t)payload_bytes + (size_t)n_records * (h->qpass ? 48 : 16) + 4096;
   if (int rc = ensure(h, h->d_cores, (size_t)n_records * sizeof(ReadCore) + 256, (size_t)h->n_reads * sizeof(ReadCore))) return rc;
   if (int rc = ensure(h, h->d_blob, blob, (size_t)h->blob_used * 8)) return rc;
   return BP_OK;
@@ -1025,7 +1027,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       int64_t g1 = i1;
       uint64_t ga = 0, gq = 0;
       while (g1 < S.n && g1 - i1 < kGroupRecs && (size_t)(g1 - i0) < kStageReads) {
-        const uint64_t a = base_part_bytes(S.n_cigar[g1], plen(S.l_seq[g1])), q = qual_part_bytes(plen(S.l_seq[g1]));
+        const uint64_t a = base_part_bytes(S.n_cigar[g1], plen(S.l_seq[g1]), h->qpass), q = qual_part_bytes(plen(S.l_seq[g1]));
         if (a + q > kGroupBytes) return fail(h, BP_EINVAL, "%s: record payload of %llu bytes", who, (unsigned long long)(a + q));
         if (ga + gq + a + q > kGroupBytes) break;
         ga += a;
@@ -1039,7 +1041,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       for (int64_t i = i1; i < g1; i++) {
         boff.push_back(ao);
         qoff.push_back(qo);
-        ao += base_part_bytes(S.n_cigar[i], plen(S.l_seq[i]));
+        ao += base_part_bytes(S.n_cigar[i], plen(S.l_seq[i]), h->qpass);
         qo += qual_part_bytes(plen(S.l_seq[i]));
       }
       bytes += ga + gq;
@@ -1138,7 +1140,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       h->prof[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
       HIP_TRY(h, hipMemcpyAsync(h->d_pack.p, st->items, ns * sizeof(PackItem), hipMemcpyHostToDevice, h->stream));
       launch_pack((const uint8_t*)h->d_raw.p, (const PackItem*)h->d_pack.p, (int64_t)ns, (ReadCore*)h->d_cores.p + h->n_reads,
-                  (uint8_t*)h->d_blob.p, h->stream);
+                  (uint8_t*)h->d_blob.p, h->qpass ? 1 : 0, h->o.min_base_qual, h->o.clip, h->stream);
       HIP_TRY(h, hipGetLastError());
     } else {
       const bp_record_batch* b = S.b;
@@ -1176,8 +1178,36 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
             const uint8_t* sp = b->seq + b->seq_off[i];
             for (uint32_t x = 0; x < sb; x++) d[x] = (uint8_t)((sp[x] << 4) | (sp[x] >> 4));
           }
-          const uint64_t tail = base_part_bytes(n_cigar, l) - (uint64_t)ncp * 4 - sb;
+          const uint64_t tail = base_part_bytes(n_cigar, l, h->qpass) - (uint64_t)ncp * 4 - sb;
           memset(d + sb, 0, (size_t)tail);
+          if (h->qpass) {
+            // one bit per base: its quality, after clipQuals (pileup_support.go:51-69), passes addBase's
+            // test (pileup.go:227); the counting kernel reads these instead of the quals
+            // (8 quals at a time from the zero-padded copy just made: byte flags by SWAR compare,
+            // gathered into one byte by a multiply)
+            uint8_t* m = d + 4 * (size_t)U;
+            const uint32_t clip = (uint32_t)h->o.clip, minq = (uint32_t)h->o.min_base_qual;
+            const uint64_t H = 0x8080808080808080ull, m8 = minq * 0x0101010101010101ull;
+            const bool all_clipped = clip > 0 && 2 * clip >= l;
+            for (uint32_t j = 0; j < U; j++) {
+              uint64_t w;
+              memcpy(&w, dq + 8 * (size_t)j, 8);
+              const uint64_t f = (((w | H) - m8) | w) & H;
+              uint32_t bits = (uint32_t)(((f >> 7) * 0x0102040810204080ull) >> 56);
+              if (clip > 0) {
+                const uint32_t x0 = 8 * j, n = l - x0 < 8 ? l - x0 : 8;  // bases of this byte
+                uint32_t cm = 0;  // the clipped ones among them
+                if (all_clipped) {
+                  cm = (1u << n) - 1u;
+                } else {
+                  if (x0 < clip) cm |= (1u << (clip - x0 < 8 ? clip - x0 : 8)) - 1u;
+                  if (x0 + 8 > l - clip) cm |= ((1u << n) - 1u) & ~((1u << (l - clip > x0 ? l - clip - x0 : 0)) - 1u);
+                }
+                bits = minq <= 2 ? (bits | cm) : (bits & ~cm);
+              }
+              m[j] = (uint8_t)bits;
+            }
+          }
           local += 32 + 4 * (int64_t)n_cigar + ((int64_t)b->l_seq[i] + 1) / 2 + b->l_seq[i];
         }
         algo.fetch_add(local);
@@ -1332,6 +1362,7 @@ static void fill_params(bp_handle* h, KernelParams& P) {
   P.mapq = h->o.mapq;
   P.min_base_qual = h->o.min_base_qual;
   P.stitch = h->o.stitch;
+  P.qpass = h->qpass ? 1 : 0;
   P.ignore_strand = h->o.ignore_strand;
   P.strand_req = h->o.strand_req;
 }

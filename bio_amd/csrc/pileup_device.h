@@ -38,6 +38,13 @@ enum : uint8_t {
 //   base part   uint32 cigar[n_cigar rounded up to even]
 //               uint8  seq4[4*U]   packed 4-bit bases (BAM codes), first base of a byte in the
 //                                  LOW nibble (BAM has it in the high one); pad nibbles 0
+//               uint8  qpass[U]    only in jobs with a quality rule and no stitching: bit k of
+//                                  byte j = base 8j+k passes it, i.e. its quality, after clipQuals
+//                                  (pileup_support.go:51-69), is >= min_base_qual (addBase,
+//                                  pileup.go:227).  Both are job options, so the packer can say
+//                                  per base what the counting kernel would work out from the qual:
+//                                  that kernel then loads 4 bytes per unit of 32 bases instead of
+//                                  36, and the clip variant is the same kernel.  Padded to a dword.
 //               pad to 8 bytes
 //   qual part   uint8  qual[8*U]   pad bytes 0
 // Records are packed in groups of up to kGroupRecs: the base parts of a group back to back,
@@ -47,13 +54,16 @@ enum : uint8_t {
 constexpr int kGroupRecs = 128;
 constexpr uint64_t kGroupBytes = 400 << 10;  // keeps qdelta (16 bits of 8-byte units) in range
 inline uint32_t blob_units(uint32_t l_seq) { return (l_seq + 7) >> 3; }
-inline uint64_t base_part_bytes(uint32_t n_cigar, uint32_t l_seq) {
-  uint64_t b = (uint64_t)((n_cigar + 1) & ~1u) * 4 + 4 * (uint64_t)blob_units(l_seq);
+// qpass: the base part ends with one bit per base, "this base passes the job's quality rule"
+// (bit k of byte j = base 8j + k; U bytes padded to a dword), see KernelParams.qpass.
+inline uint64_t base_part_bytes(uint32_t n_cigar, uint32_t l_seq, bool qpass = false) {
+  const uint64_t U = blob_units(l_seq);
+  uint64_t b = (uint64_t)((n_cigar + 1) & ~1u) * 4 + 4 * U + (qpass ? 4 * ((U + 3) >> 2) : 0);
   return (b + 7) & ~(uint64_t)7;
 }
 inline uint64_t qual_part_bytes(uint32_t l_seq) { return 8 * (uint64_t)blob_units(l_seq); }
-inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq) {
-  return base_part_bytes(n_cigar, l_seq) + qual_part_bytes(l_seq);
+inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq, bool qpass = false) {
+  return base_part_bytes(n_cigar, l_seq, qpass) + qual_part_bytes(l_seq);
 }
 
 // A genomic window: at most W consecutive positions of one reference, covering BED
@@ -122,6 +132,7 @@ struct KernelParams {
   int32_t max_span;           // largest (clamped) span among submitted records
   // options (bp_opts)
   int32_t clip, flag_exclude, mapq, min_base_qual, stitch, ignore_strand, strand_req;
+  int32_t qpass;              // the payloads carry pass bits (see the payload layout)
 };
 
 // One entry of a per-read feature list = PerReadFeatures (pileup/snp/row.go:22-31), 6 bytes.

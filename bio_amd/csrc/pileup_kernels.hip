@@ -205,6 +205,10 @@ struct SegExtra {
   // s_mx = read index of its first base | mate qdelta << 16
   uint4 s_mate[kSegCapExtra];
   uint32_t s_mx[kSegCapExtra];
+  // where the unit loader finds the pass bits of the segment's first unit (the segment record's
+  // own offset field says where its quals are, which the overlap groups need): byte offset from
+  // the first unit's bases << 5 | bit shift
+  uint32_t s_qp[kSegCapExtra];
   uint8_t qthr[96];             // KernelParams::qthr, "never" clamped to 96
   // stitch: the unit slots of this round with positions that the record's mate covers too and
   // that this record has to decide (it found its mate); filled by phase 1 (0xffff: void)
@@ -318,7 +322,7 @@ __device__ __forceinline__ bool seg_extent(const SegIn& g, uint32_t wlen, int32_
   return true;
 }
 
-template <bool EXTRA>
+template <bool EXTRA, bool QP>
 __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, uint32_t us, const SegIn& g,
                                           int32_t s1, int32_t e1, uint32_t jlo, uint32_t U, uint32_t blob,
                                           uint32_t lseqnc, uint32_t qdelta, uint32_t sslot, int32_t rec,
@@ -337,8 +341,16 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
   r.x = (uint32_t)sa;
   r.y = (uint32_t)(sa >> 32) | (noff << 3) | (sslot << 6) | (((uint32_t)s1 & 31u) << 8) |
         (((uint32_t)(e1 - 1) & 31u) << 13) | ((U - 1) << 24);
-  r.z = us | (jlo << 16) | (((uint32_t)qo & 3u) << 24);
-  r.w = (uint32_t)((qo & ~3) - (so & ~3));
+  // pass bits: bit b_first of the record's bit string, which lies behind its packed bases (4 bytes
+  // per 8-base unit of the whole read); b_first may be < 0 (>= -31)
+  [[maybe_unused]] const int32_t mb = (cigb + 4 * (int32_t)(((lseqnc & 0xffffu) + 7u) >> 3)) * 8 + b_first;
+  if constexpr (QP && !EXTRA) {
+    r.z = us | (jlo << 16) | (((uint32_t)mb & 31u) << 24);
+    r.w = (uint32_t)(((mb >> 5) << 2) - (so & ~3));
+  } else {
+    r.z = us | (jlo << 16) | (((uint32_t)qo & 3u) << 24);
+    r.w = (uint32_t)((qo & ~3) - (so & ~3));
+  }
   S.seg[idx] = r;
   if constexpr (EXTRA) {
     S.ex.s_ref[idx] = g.sref;
@@ -347,6 +359,7 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
     S.ex.s_rec[idx] = rec;
     S.ex.s_mate[idx] = minfo;
     S.ex.s_mx[idx] = mx;
+    if constexpr (QP) S.ex.s_qp[idx] = ((uint32_t)(((mb >> 5) << 2) - (so & ~3)) << 5) | ((uint32_t)mb & 31u);
   }
   for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
 }
@@ -369,7 +382,7 @@ __device__ __forceinline__ uint32_t overlap_units(int32_t s1, int32_t e1, uint32
   return (((uint32_t)(hi - 1) >> 5) - jlo) - first + 1u;
 }
 
-template <bool EXTRA, bool STITCH>
+template <bool EXTRA, bool STITCH, bool QP>
 __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
                                           const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
                                           uint32_t qdelta, uint32_t sslot, int32_t rec, uint32_t par, uint4 miA,
@@ -402,9 +415,9 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
   const uint32_t idx = base_s + (excl >> 23), us = (base_lo & 0xffffu) + (excl & 0x1fffu);
   const bool ok = idx + nseg <= (uint32_t)seg_cap<EXTRA>() && us + U <= (uint32_t)kUnitCap;
   if (ok) {
-    if (realA) write_seg(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, qdelta, sslot, rec, miA, mxA);
+    if (realA) write_seg<EXTRA, QP>(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, qdelta, sslot, rec, miA, mxA);
     if (realB)
-      write_seg(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, qdelta, sslot, rec, miB, mxB);
+      write_seg<EXTRA, QP>(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, qdelta, sslot, rec, miB, mxB);
   } else {
     for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
   }
@@ -424,19 +437,24 @@ __device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, co
 
 // One unit in flight: the loaded bytes and everything processing needs, so that the plain
 // path does not touch the segment list again.
-template <bool NEED_Q, bool STITCH = false>
+// QM: what the unit brings of the quals. 0 nothing (min_base_qual 0 without stitching: every base
+// passes), 2 the 32 pass bits the packer left behind the bases (KernelParams.qpass).  (1 was the
+// 32 quals themselves, 36 bytes: the plain pass compared them with min_base_qual and worked out
+// the clip masks itself until the packers took that over; 5.73 -> 4.67 ms on chr1 30x
+// -min-base-qual 20.  The overlap groups of stitched runs still load quals: they need the values.)
+template <int QM, bool STITCH = false>
 struct UnitLoad {
   uint32_t sd[5];                  // 20 bytes covering the unit's 32 packed bases
-  uint32_t qd[NEED_Q ? 9 : 1];     // 36 bytes covering the unit's 32 quals
+  uint32_t qd[QM == 2 ? 2 : 1];    // 8 bytes covering the unit's pass bits
   uint32_t mask;                   // valid positions of the unit
   uint32_t meta;                   // 0..5 window unit | 6..8 nibble shift | 9..10 qual byte shift |
-                                   // 11 strand slot | 16 active
+                                   // 11 strand slot | 16 active | 17..21 bit shift of the pass bits
   uint32_t seg;                    // segment (stitched / clipped paths)
 };
 
 // Loads are issued unconditionally (inactive lanes read the start of the payload buffer) so
 // that every issue is the same number of VMEM instructions and the counted vmcnt waits stay
-// exact.  NEED_Q = false (min_base_qual 0, no stitching: every base passes the quality rule,
+// exact.  QM = 0 (min_base_qual 0, no stitching: every base passes the quality rule,
 // pileup.go:227) skips the qual loads altogether.
 // Slot order: neighbouring segments overlap on the genome, and lanes of one instruction
 // that add to the same counter serialise.  Chunks of BP_CHUNK consecutive slots (part of
@@ -470,9 +488,9 @@ __device__ __forceinline__ uint32_t mate_overlap(const SH& S, uint32_t s, uint32
   return h2 - l2 >= 32 ? 0xffffffffu : ((1u << (h2 - l2)) - 1u) << l2;
 }
 
-template <bool NEED_Q, bool STITCH, bool EXTRA>
+template <int QM, bool STITCH, bool EXTRA>
 __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<EXTRA>& S, uint32_t t,
-                                           uint32_t T, UnitLoad<NEED_Q, STITCH>& L) {
+                                           uint32_t T, UnitLoad<QM, STITCH>& L) {
   bool in = t < T;
   uint32_t s = S.owner[in ? t : 0];
   if (s == 0xffffu) { in = false; s = 0; }
@@ -483,18 +501,22 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
                   (u == ((r.y >> 24) & 0x3fu) ? 0xffffffffu >> (31u - ((r.y >> 13) & 31u)) : 0xffffffffu);
   L.mask = in ? mask : 0u;
   L.seg = s;
-  L.meta = (in ? jj | 0x10000u : 0u) | (((r.y >> 3) & 7u) << 6) | (((r.z >> 24) & 3u) << 9) |
-           (((r.y >> 6) & 1u) << 11);
+  uint32_t qpo = r.w, qps = (r.z >> 24) & 31u;  // QM == 2: where the pass bits are
+  if constexpr (QM == 2 && EXTRA) {
+    const uint32_t v = S.ex.s_qp[s];
+    qpo = v >> 5;
+    qps = v & 31u;
+  }
+  L.meta = (in ? jj | 0x10000u : 0u) | (((r.y >> 3) & 7u) << 6) |
+           (QM == 2 ? qps << 17 : ((r.z >> 24) & 3u) << 9) | (((r.y >> 6) & 1u) << 11);
   uint64_t off = (((uint64_t)(r.y & 7u) << 32) | r.x) + 16u * u;
   if (!in) off = 0;
   const uint8_t* sp = P.blob + off;
-  if constexpr (NEED_Q) {
-    const uint8_t* qp = sp + (in ? (int64_t)(int32_t)r.w + 16 * (int64_t)u : 0);
-    const u32x4a q0 = *(const u32x4a*)qp;
-    const u32x4a q1 = *(const u32x4a*)(qp + 16);
-    L.qd[8] = *(const uint32_t*)(qp + 32);
-    L.qd[0] = q0.x; L.qd[1] = q0.y; L.qd[2] = q0.z; L.qd[3] = q0.w;
-    L.qd[4] = q1.x; L.qd[5] = q1.y; L.qd[6] = q1.z; L.qd[7] = q1.w;
+  if constexpr (QM == 2) {
+    const uint8_t* mp = sp + (in ? (int64_t)(int32_t)qpo - 12 * (int64_t)u : 0);  // (sp moves 16 bytes a unit, the bits 4)
+    const u32x2a m0 = *(const u32x2a*)mp;
+    L.qd[0] = m0.x;
+    L.qd[1] = m0.y;
   }
   const u32x4a s0 = *(const u32x4a*)sp;
   L.sd[4] = *(const uint32_t*)(sp + 16);
@@ -674,10 +696,8 @@ __device__ __forceinline__ void process_ov_group(const KernelParams& P, SH& B, c
 // alone, and only the positions the record's mate also covers are patched afterwards
 // (addReadPair, pileup.go:406-446): the record that was stored first drops them, the one that
 // found its mate decides them from both reads (equal bases: qualSumTable threshold, else X).
-template <bool STITCH, bool CLIP, bool MINQ0, class SH>
-__device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B,
-                                                   const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t cpo) {
-  static_assert(!(STITCH && MINQ0), "the stitched path always reads the quals");
+template <int QM, class SH>
+__device__ __forceinline__ void process_unit_plain(SH& B, const UnitLoad<QM, false>& L, uint32_t cpo) {
   constexpr uint32_t M1 = 0x11111111u;
   const uint32_t meta = L.meta;
   const uint32_t jj = meta & 0x3fu;
@@ -696,41 +716,12 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B,
     const uint32_t oh = (xx ^ (xx >> 2)) & ~(a | (a >> 2)) & M1;      // exactly one bit set
     const uint32_t oh3 = oh | (oh << 1);
     uint32_t cw = (lg & oh3) + ((oh ^ M1) << 2);                      // one-hot ? log2 : 4 (X)
-    if constexpr (!MINQ0) {
-      // quality rule on the 8 quals at once: byte flag 0x80 = qual >= min_base_qual
-      const uint32_t qsh = (meta >> 9) & 3u;
-      const uint32_t qlo = __builtin_amdgcn_alignbyte(L.qd[2 * m + 1], L.qd[2 * m], qsh);
-      const uint32_t qhi = __builtin_amdgcn_alignbyte(L.qd[2 * m + 2], L.qd[2 * m + 1], qsh);
-      constexpr uint32_t H = 0x80808080u;
-      const uint32_t minq4 = (uint32_t)P.min_base_qual * 0x01010101u;
-      uint32_t mlo = (((qlo | H) - minq4) | qlo) & H;
-      uint32_t mhi = (((qhi | H) - minq4) | qhi) & H;
-      // byte flags (bits 7,15,23,31) -> nibble-spaced flags (bits 7,11,15,19)
-      mlo = (mlo | (mlo >> 4)) & 0x08800880u;
-      mlo = (mlo | (mlo >> 8)) & 0x00088880u;
-      mhi = (mhi | (mhi >> 4)) & 0x08800880u;
-      mhi = (mhi | (mhi >> 8)) & 0x00088880u;
-      uint32_t pn = (mlo >> 7) | (mhi << 9);  // bit 4k = base k passes
-      // (tried: even/odd quals gathered with v_perm so that the byte flags fall on the nibbles
-      // directly, 5 % fewer VALU instructions in all; 3 % slower on chr1 30x -min-base-qual 20:
-      // the time went to waits, not to issue)
-      if constexpr (CLIP) {
-        // clipQuals (pileup_support.go:51-69): the first and last `clip` bases of the read
-        // have quality 2
-        const uint32_t sg = L.seg;
-        const int32_t b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + ((int32_t)((4 * jj + m) * 8) - B.ex.s_ref[sg]);
-        const int32_t lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
-        const int32_t clip = P.clip;
-        int32_t nlo = clip - b0;                 // bases k < nlo are clipped
-        int32_t nhi = lseq - clip - b0;          // bases k >= nhi are clipped
-        if (2 * clip >= lseq) nlo = 8;
-        nlo = nlo < 0 ? 0 : (nlo > 8 ? 8 : nlo);
-        nhi = nhi < 0 ? 0 : (nhi > 8 ? 8 : nhi);
-        const uint32_t lo_m = nlo >= 8 ? M1 : (M1 & ((1u << (4 * nlo)) - 1u));
-        const uint32_t hi_m = nhi >= 8 ? 0u : (M1 & ~((1u << (4 * nhi)) - 1u));
-        const uint32_t cm = lo_m | hi_m;
-        pn = (uint32_t)P.min_base_qual <= 2u ? (pn | cm) : (pn & ~cm);
-      }
+    if constexpr (QM == 2) {
+      // the packer's pass bits (quality rule and clip already applied): 8 bits -> bit 4k
+      uint32_t pn = (__builtin_amdgcn_alignbit(L.qd[1], L.qd[0], (meta >> 17) & 31u) >> (8 * m)) & 0xffu;
+      pn = (pn | (pn << 12)) & 0x000f000fu;
+      pn = (pn | (pn << 6)) & 0x03030303u;
+      pn = (pn | (pn << 3)) & M1;
       const uint32_t pn15 = (pn << 4) - pn;     // 0xf per passing base
       const uint32_t cf = 0x44444444u | oh;     // failing: base -> depth-only (5), X stays X (4)
       cw = (cw & pn15) | (cf & ~pn15);
@@ -746,12 +737,6 @@ __device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B,
       }
     }
   }
-}
-
-template <bool STITCH, bool CLIP, bool MINQ0, class SH>
-__device__ __forceinline__ void unit(const KernelParams& P, SH& B,
-                                     const UnitLoad<STITCH || !MINQ0, STITCH>& L, uint32_t cpo) {
-  process_unit_plain<STITCH, CLIP, MINQ0 && !STITCH>(P, B, L, cpo);
 }
 
 // Advance the CIGAR cursor (c, r, q) = (op index, window position, read index) to the next M
@@ -856,7 +841,9 @@ __device__ __forceinline__ Window uni_window(const Window& v) {
 // first launch wrote.
 template <bool STITCH, bool CLIP, bool MINQ0, bool DEEP>
 __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParams P) {
-  constexpr bool NEED_Q = STITCH || !MINQ0;
+  // what a unit brings of the quals: the packer's pass bits (KernelParams.qpass), or nothing (every
+  // base passes)
+  constexpr int QM = MINQ0 ? 0 : 2;
   constexpr bool EXTRA = STITCH || CLIP;
   __shared__ BlockSharedT<EXTRA> S;
   const int tid = threadIdx.x;
@@ -1165,7 +1152,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         }
         if (!__any(wantA)) break;
-        const bool ok = emit_wave<EXTRA, STITCH>(S, wantA, A, wantB, B, wlen, blob, lseqnc, qdelta, sslot, rec, par, miA, mxA, miB, mxB);
+        const bool ok = emit_wave<EXTRA, STITCH, !MINQ0>(S, wantA, A, wantB, B, wlen, blob, lseqnc, qdelta, sslot, rec, par, miA, mxA, miB, mxB);
         if (wantA) {
           if (!ok) {
             failed = true;
@@ -1274,11 +1261,11 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       {
         unsigned long long a_issue = 0, a_wait = 0, a_proc = 0;
         for (uint32_t tb = wbase; tb < T; tb += kBlock) {
-          UnitLoad<NEED_Q, STITCH> L1;
+          UnitLoad<QM, false> L1;
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t0 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          issue_unit<NEED_Q, STITCH>(P, S, slot_of(tb + (tid & 63), T, (T + 63) / 64), T, L1);
+          issue_unit<QM, false>(P, S, slot_of(tb + (tid & 63), T, (T + 63) / 64), T, L1);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1287,7 +1274,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t2 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          unit<STITCH, CLIP, MINQ0>(P, S, L1, cpo);
+          process_unit_plain<QM>(S, L1, cpo);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -1314,13 +1301,13 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // comes FIRST, its loads issued together with the first plain unit's: the round trip is
         // shared.  So the bulk of the units runs at the plain path's depth and register budget,
         // and the mate's loads are issued only where they are used.
-        constexpr int kD = NEED_Q ? (CLIP ? 1 : kDepthQ) : kDepth;
+        constexpr int kD = STITCH ? (CLIP ? 1 : kDepthQ) : kDepth;
         const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
         const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
-        UnitLoad<NEED_Q, false> L[kD];
+        UnitLoad<QM, false> L[kD];
         uint32_t t = (uint32_t)tid;
-        auto issue1 = [&](UnitLoad<NEED_Q, false>& U, uint32_t tt) {
-          issue_unit<NEED_Q, false>(P, S, slot_of(tt, T, R), T, U);
+        auto issue1 = [&](UnitLoad<QM, false>& U, uint32_t tt) {
+          issue_unit<QM, false>(P, S, slot_of(tt, T, R), T, U);
           if constexpr (STITCH) {
             bool second = false;
             if (U.meta & 0x10000u) U.mask &= ~mate_overlap(S, U.seg, U.meta & 0x3fu, second);
@@ -1359,7 +1346,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         for (; it + kD < n_it; it += kD) {
 #pragma unroll
           for (int d = 0; d < kD; d++) {
-            unit<false, CLIP, MINQ0>(P, S, L[d], cpo);
+            process_unit_plain<QM>(S, L[d], cpo);
             issue1(L[d], t);
             t += kBlock;
           }
@@ -1367,7 +1354,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         const uint32_t rem = n_it - it;
 #pragma unroll
         for (int d = 0; d < kD; d++)
-          if ((uint32_t)d < rem) unit<false, CLIP, MINQ0>(P, S, L[d], cpo);
+          if ((uint32_t)d < rem) process_unit_plain<QM>(S, L[d], cpo);
       }
 #endif
       if constexpr (LATE) prefetch_next();
@@ -2082,8 +2069,8 @@ static void launch_pileup_variant(const KernelParams& P, dim3 g, hipStream_t s) 
     // every base passes the quality rule, clipped or not: the quals are never read
     hipLaunchKernelGGL((pileup_kernel<false, false, true, DEEP>), g, b, 0, s, P);
   } else {
-    if (clip) hipLaunchKernelGGL((pileup_kernel<false, true, false, DEEP>), g, b, 0, s, P);
-    else hipLaunchKernelGGL((pileup_kernel<false, false, false, DEEP>), g, b, 0, s, P);
+    // quality rule and clip are in the packer's pass bits: one variant
+    hipLaunchKernelGGL((pileup_kernel<false, false, false, DEEP>), g, b, 0, s, P);
   }
 }
 

@@ -1031,9 +1031,6 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // The record's entry of the mate table (MateEntry, pileup_device.h) says everything
         // phase 1 needs to know of the mate, so the mate's core is never fetched: one load
         // beside the record's own core instead of two dependent ones behind it.
-#ifdef BP_EXP_NOMATE
-        me.x = 0;
-#endif
         if (keep && (me.x & MATE_HAS)) {
           const int32_t delta = ((int32_t)(me.x << 15)) >> 15;  // mate start - own start, 17 bits signed
           const uint32_t second = (me.x & MATE_SECOND) ? 1u : 0u;
@@ -1064,21 +1061,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     constexpr bool LATE = STITCH;
     [[maybe_unused]] bool first_round = true;
     if constexpr (LATE) {
-#if defined(BP_EXP_NOPF)
-      if (rec < r1) {
-        const uint4* cp = (const uint4*)(P.cores + rec);
-        decode(cp[0], cp[1], ((const uint4*)P.mate)[rec]);
-      }
-#elif defined(BP_EXP_SLIMPF)
-      if (rec < r1) {
-        const uint4* cp = (const uint4*)(P.cores + rec);
-        uint4 me = make_uint4(pme.x, 0, 0, 0);
-        if (pme.x & MATE_HAS) me = ((const uint4*)P.mate)[rec];
-        decode(pc0, cp[1], me);
-      }
-#else
       if (rec < r1) decode(pc0, pc1, pme);
-#endif
     }
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
     [[maybe_unused]] uint4 nme = nc0;
@@ -1219,17 +1202,9 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
             if constexpr (LATE) n_win = uni_window(n_win);
             if (n_r0 + tid < n_r1) {
               const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
-#if defined(BP_EXP_NOPF)
-              if constexpr (!LATE) { nc0 = cp[0]; nc1 = cp[1]; }
-#elif defined(BP_EXP_SLIMPF)
-              nc0 = cp[0];
-              if constexpr (!LATE) nc1 = cp[1];
-              if constexpr (STITCH) nme.x = ((const uint32_t*)P.mate)[4 * (n_r0 + tid)];
-#else
               nc0 = cp[0];
               nc1 = cp[1];
               if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
-#endif
             }
             if (item + 2 < w_last) {
               nn_r0 = P.win_r0[item + 2];
@@ -1290,17 +1265,16 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // Every thread runs n_it unit slots (block-uniform).  The steady-state loop has no
         // branch in its body, so the compiler's counted vmcnt waits keep kD units' loads in
         // flight; at 30x a window is 2-3 units per thread and the loop body rarely runs.
-        // (with -clip one unit in flight: 6.40 -> 5.97 ms on chr1 30x; the clip masks' registers
-        // are what a second unit's loads would have to live next to)
+        // (stitched with -clip: one unit in flight, the overlap groups' clip masks need the room)
         // Stitched runs treat a unit in two parts.  Every unit goes through the plain path with
-        // the quality rule, leaving out the positions the record's mate covers too (Depth++ once
-        // per pair position, pileup.go:409-430).  The units whose record has to decide such
+        // the packer's pass bits, leaving out the positions the record's mate covers too (Depth++
+        // once per pair position, pileup.go:409-430).  The units whose record has to decide such
         // positions (it found its mate in the table) were listed by phase 1 - few at whole-genome
-        // insert sizes; for them the mate's bases and quals are loaded next to the record's own
-        // and just those positions are counted (process_unit_plain's stitched branch).  That
-        // comes FIRST, its loads issued together with the first plain unit's: the round trip is
-        // shared.  So the bulk of the units runs at the plain path's depth and register budget,
-        // and the mate's loads are issued only where they are used.
+        // insert sizes; for them the mate's bases and quals are loaded next to the record's own,
+        // 8 positions to a lane (OvGroup), and just those positions are counted.  That comes
+        // FIRST, its loads issued together with the first plain unit's: the round trip is shared.
+        // So the bulk of the units runs at the plain path's register budget, and the mate's
+        // loads are issued only where they are used.
         constexpr int kD = STITCH ? (CLIP ? 1 : kDepthQ) : kDepth;
         const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
         const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
@@ -1314,11 +1288,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         };
         if constexpr (STITCH) {
-#ifdef BP_EXP_NO2B
-          const uint32_t n_ovl_ = 0;
-#else
           const uint32_t n_ovl_ = n_ovl;
-#endif
           if (n_ovl_ != 0) {  // block-uniform
             OvGroup G;
             issue_ov_group(P, S, (uint32_t)tid, n_ovl_, T, cpo, G);

@@ -287,6 +287,7 @@ struct bp_handle {
   bool mate_dirty = true;                             // changed since it was last copied to the device
   FirstReadTable stored[kMatePartitions];  // by name hash (scan_slice)
   std::vector<PairOut> pair_out[kMatePartitions];
+  std::vector<uint32_t> lay_a, lay_q;  // bp_submit: payload part sizes of the call's records
   std::vector<PairItem> pair_items;   // of the slice, chunk by chunk, each chunk's in partition order
   std::vector<uint32_t> pair_start;   // [chunk][partition] -> first item; kMatePartitions + 1 entries a chunk
   std::vector<uint8_t> scan_cls;
@@ -941,6 +942,7 @@ int bp_reserve(bp_handle* h, int64_t n_records, int64_t payload_bytes) {
   if (!h || n_records < 0 || payload_bytes < 0) return fail(h, BP_EINVAL, "bp_reserve: bad argument");
   HIP_TRY(h, hipSetDevice(h->device));
   // payload grows by padding: cigar to even count, qual/seq to whole 8-base units
+  if (h->o.stitch) h->mate.reserve((size_t)n_records);
   size_t blob = (size_t)payload_bytes + (size_t)n_records * (h->qpass ? 48 : 16) + 4096;
   if (int rc = ensure(h, h->d_cores, (size_t)n_records * sizeof(ReadCore) + 256, (size_t)h->n_reads * sizeof(ReadCore))) return rc;
   if (int rc = ensure(h, h->d_blob, blob, (size_t)h->blob_used * 8)) return rc;
@@ -1014,20 +1016,38 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
   std::vector<uint32_t> gsrc;
   // a record longer than the core can say (0xffff) passes no max-read-len: no payload kept
   auto plen = [](uint32_t l) { return l > 0xffffu ? 0u : l; };
+  // payload part sizes of every record of the call, on all threads: the layout loop below is
+  // serial (a group closes when it is full) and otherwise spends its time working these out
+  std::vector<uint32_t>& sz_a = h->lay_a;
+  std::vector<uint32_t>& sz_q = h->lay_q;
+  {
+    const double t_sz = now_s();
+    sz_a.resize((size_t)S.n);
+    sz_q.resize((size_t)S.n);
+    const size_t szchunk = 16384;
+    parallel_for(((size_t)S.n + szchunk - 1) / szchunk, nthreads, [&](size_t c) {
+      for (size_t i = c * szchunk; i < std::min((size_t)S.n, (c + 1) * szchunk); i++) {
+        // (a record's parts stay far below 4 GiB: l_seq <= 0xffff here, n_cigar <= 0xffff is checked by the scan)
+        sz_a[i] = (uint32_t)std::min<uint64_t>(base_part_bytes(S.n_cigar[i], plen(S.l_seq[i]), h->qpass), 0xffffffffull);
+        sz_q[i] = (uint32_t)qual_part_bytes(plen(S.l_seq[i]));
+      }
+    });
+    h->prof[1] += now_s() - t_sz;
+  }
   int64_t i0 = 0;
   while (i0 < S.n) {
     // slice bounded by staging capacity
     int64_t i1 = i0;
     uint64_t bytes = 0;
     const double t_layout = now_s();
-    boff.clear();
-    qoff.clear();
+    boff.resize(std::min<size_t>((size_t)(S.n - i0), kStageReads));
+    qoff.resize(boff.size());
     while (i1 < S.n && (size_t)(i1 - i0) < kStageReads) {
       // one group: base parts back to back, then the qual parts
       int64_t g1 = i1;
       uint64_t ga = 0, gq = 0;
       while (g1 < S.n && g1 - i1 < kGroupRecs && (size_t)(g1 - i0) < kStageReads) {
-        const uint64_t a = base_part_bytes(S.n_cigar[g1], plen(S.l_seq[g1]), h->qpass), q = qual_part_bytes(plen(S.l_seq[g1]));
+        const uint64_t a = sz_a[(size_t)g1], q = sz_q[(size_t)g1];
         if (a + q > kGroupBytes) return fail(h, BP_EINVAL, "%s: record payload of %llu bytes", who, (unsigned long long)(a + q));
         if (ga + gq + a + q > kGroupBytes) break;
         ga += a;
@@ -1039,15 +1059,17 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       if (stream_mode && g1 > i0 && (uint64_t)S.off[g1 - 1] + S.rec_bytes[g1 - 1] - S.off[i0] > kStageBlob && i1 > i0) break;
       uint64_t ao = bytes, qo = bytes + ga;
       for (int64_t i = i1; i < g1; i++) {
-        boff.push_back(ao);
-        qoff.push_back(qo);
-        ao += base_part_bytes(S.n_cigar[i], plen(S.l_seq[i]), h->qpass);
-        qo += qual_part_bytes(plen(S.l_seq[i]));
+        boff[(size_t)(i - i0)] = ao;
+        qoff[(size_t)(i - i0)] = qo;
+        ao += sz_a[(size_t)i];
+        qo += sz_q[(size_t)i];
       }
       bytes += ga + gq;
       i1 = g1;
     }
     const size_t ns = (size_t)(i1 - i0);
+    boff.resize(ns);
+    qoff.resize(ns);
     h->prof[1] += now_s() - t_layout;
     if ((uint64_t)h->blob_used + bytes / 8 > 0xffffffffull)
       return fail(h, BP_ENOMEM, "%s: more than 32 GiB of record payload in one job", who);

@@ -508,3 +508,44 @@ def test_host_renderer_writes_the_same_files(tmp_path, monkeypatch):
         for f in files:
             a, b = c.read("dev." + f), c.read("cpu." + f)
             assert a == b and a.count("\n") > 100, f
+
+
+@pytest.mark.parametrize("stitch", [False, True])
+def test_many_chunks_and_jobs_at_12mb(tmp_path, monkeypatch, stitch):
+    """The reader's chunk pipeline at a size where it matters: 12 Mb at 30x (2.4 M records, 0.65 GB
+    inflated = 40 chunks of 16 MiB), cut into 6 jobs so that chunks cross job boundaries and the
+    padding of the next job (handed-over-whole chunks, record-by-record chunks and stashed pieces
+    all occur), against the oracle's rows for every position; once more with small chunks and a
+    quality rule with clip."""
+    import pandas as pd
+    from bio_amd import synth
+    L = 12_000_000
+    sb = synth.generate([(0, 0, L - 1000, 30.0)], with_names=True, threads=8)
+    rb = sb.to_record_batch()
+    bam, fa, bedp = str(tmp_path / "in.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "all.bed")
+    host.bam_write(bam, ["chr1"], [L], rb, level=1, threads=8)
+    rng = np.random.default_rng(3)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
+    with open(fa, "wb") as f:
+        f.write(b">chr1\n" + seq.tobytes() + b"\n")
+    bamio.write_bed(bedp, [(0, 0, L)], ["chr1"])
+    monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(1 << 21))
+
+    def check(out, **okw):
+        t = pd.read_csv(out + ".basestrand.tsv", sep="\t")
+        want = O.pileup(O.make_opts(**okw), [L], {0: [[0, L]]}, rb)
+        assert len(t) == L and (t["POS"].to_numpy() == np.arange(1, L + 1)).all()
+        got = t[["A+", "A-", "C+", "C-", "G+", "G-", "T+", "T-"]].to_numpy(np.uint32)
+        bad = np.nonzero((got != want[2][:, 1:9]).any(axis=1))[0]
+        assert len(bad) == 0, (len(bad), bad[:5])
+        assert (t["REF"].to_numpy().astype("S1").view(np.uint8) == seq).all()
+        assert int(want[2][:, 0].sum()) > 2.5e8
+
+    out = str(tmp_path / "o")
+    host.pileup(bam, fa, "basestrand-tsv", out, Opts(BedPath=bedp, Stitch=stitch, MinBaseQual=20 if stitch else 0))
+    check(out, stitch=int(stitch), min_base_qual=20 if stitch else 0)
+    if not stitch:
+        monkeypatch.setenv("BIO_PILEUP_BATCH_BLOCKS", "7")
+        host.pileup(bam, fa, "basestrand-tsv", out, Opts(BedPath=bedp, MinBaseQual=13, Clip=4))
+        check(out, min_base_qual=13, clip=4)
+    sb.close()

@@ -594,7 +594,7 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
   std::vector<uint8_t>& cls = h->scan_cls;      // (scratch kept with the handle between slices)
   std::vector<uint64_t>& hashes = h->scan_hash;
   cls.assign(ns, 0);
-  const size_t chunk = 8192;
+  const size_t chunk = 2048;  // (a 16 MiB piece of a BAM stream is ~60k records: enough tasks for every thread)
   const size_t n_chunks = (ns + chunk - 1) / chunk;
   if (o.stitch) {
     hashes.resize(ns);

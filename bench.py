@@ -128,7 +128,7 @@ def committed_traffic(cfg, kernel):
     these very kernel sources, else null."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", f"traffic_{cfg}.json")))
-        if tj["kernel_source_sha256"] == kernel_source_hash() and tj["kernel"] in kernel:
+        if tj["kernel_source_sha256"] == kernel_source_hash() and kernel in tj["kernel"]:
             return tj["traffic_bytes_per_launch"], f"profiles/traffic_{cfg}.json ({tj['source']})"
     except (OSError, ValueError, KeyError):
         pass

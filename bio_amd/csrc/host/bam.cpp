@@ -1,6 +1,8 @@
-// bam.cpp -- sequential BGZF/BAM reader feeding bp_record_batch (reference: encoding/bam
-// unmarshal.go:126-224 for the record layout, encoding/bamprovider/provider.go:141-166 for the
-// iterator contract).  BGZF blocks are inflated a batch at a time on a few host threads.
+// bam.cpp -- sequential BGZF/BAM reader (reference: encoding/bam unmarshal.go:126-224 for the
+// record layout, encoding/bamprovider/provider.go:141-166 for the iterator contract).  BGZF blocks
+// are read and inflated a batch ahead on the host threads; records are handed out one at a time
+// (Next) or as chunks of whole records as they lie in the inflated stream (NextChunk), which the
+// driver passes to bp_submit_bam.
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,32 +24,6 @@
 #include "bio_host.h"
 
 namespace bio {
-
-void RecordBatchBuilder::clear() {
-  ref_id.clear(); pos.clear(); mate_ref_id.clear(); mate_pos.clear();
-  flags.clear(); mapq.clear(); n_cigar.clear(); l_seq.clear();
-  cigar_off.clear(); seq_off.clear(); qual_off.clear(); name_off.clear();
-  cigar.clear(); seq.clear(); qual.clear(); name.clear();
-}
-
-bp_record_batch RecordBatchBuilder::view() {
-  bp_record_batch b;
-  memset(&b, 0, sizeof(b));
-  b.n = size();
-  b.ref_id = ref_id.data(); b.pos = pos.data();
-  b.mate_ref_id = mate_ref_id.data(); b.mate_pos = mate_pos.data();
-  b.flags = flags.data(); b.mapq = mapq.data();
-  b.n_cigar = n_cigar.data(); b.l_seq = l_seq.data();
-  b.cigar_off = cigar_off.data(); b.cigar = cigar.data();
-  b.seq_off = seq_off.data(); b.seq = seq.data();
-  b.qual_off = qual_off.data(); b.qual = qual.data();
-  if (keep_names) {
-    if (name_off.size() == (size_t)b.n) name_off.push_back(name.size());
-    b.name_off = name_off.data();
-    b.name = name.data();
-  }
-  return b;
-}
 
 namespace {
 inline uint16_t U16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }

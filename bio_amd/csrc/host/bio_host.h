@@ -66,20 +66,6 @@ struct NoInitAlloc : std::allocator<T> {
   template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
 };
 
-struct RecordBatchBuilder {
-  std::vector<int32_t> ref_id, pos, mate_ref_id, mate_pos;
-  std::vector<uint16_t> flags;
-  std::vector<uint8_t> mapq;
-  std::vector<uint32_t> n_cigar, l_seq;
-  std::vector<uint64_t> cigar_off, seq_off, qual_off, name_off;
-  std::vector<uint32_t, NoInitAlloc<uint32_t>> cigar;
-  std::vector<uint8_t, NoInitAlloc<uint8_t>> seq, qual, name;
-  bool keep_names = true;
-  int64_t size() const { return (int64_t)pos.size(); }
-  void clear();
-  bp_record_batch view();
-};
-
 // Sequential BGZF/BAM reader: header + alignment records in file order, decoded per
 // encoding/bam/unmarshal.go:126-224 / SAM spec 4.2.
 class BamReader {

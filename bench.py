@@ -145,7 +145,11 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
     import subprocess
     import tempfile
     from bio_amd import bamio, host
-    d = tempfile.mkdtemp(prefix="bp_e2e_", dir=os.environ.get("E2E_TMP", "/tmp"))
+    base = os.environ.get("E2E_TMP", "/tmp")
+    need = int(rb.n * 330 * 0.3 + 36 * L + 1.1 * L) + (1 << 30)  # BAM + text + FASTA, roughly
+    if shutil.disk_usage(base).free < need:
+        return {"skipped": f"less than {need / 1e9:.0f} GB free under {base} (set E2E_TMP)"}
+    d = tempfile.mkdtemp(prefix="bp_e2e_", dir=base)
     try:
         t0 = time.time()
         bam = os.path.join(d, "in.bam")
@@ -493,7 +497,12 @@ def main():
 
     e2e = None
     if rank == 0 and pworld == 1 and not args.no_e2e and cname in ("c2", "c2q", "c2c", "c2s") and not emulate:
-        e2e = e2e_block(rb, L, B, o, opts_kw, job, args.e2e_cpu_sample_mb, not args.no_cpu_baseline)
+        # (a secondary block: whatever goes wrong in it - no room for 12 GB of files under E2E_TMP, say -
+        # must not take the bench line with it)
+        try:
+            e2e = e2e_block(rb, L, B, o, opts_kw, job, args.e2e_cpu_sample_mb, not args.no_cpu_baseline)
+        except (Exception, SystemExit) as ex:
+            e2e = {"error": str(ex)[:300]}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -188,10 +188,10 @@ class Driver {
     return "";
   }
 
-  std::string SubmitPiece(const Piece& p) {
+  std::string SubmitPiece(size_t stream, const Piece& p) {
     if (p.off.empty()) return "";
-    for (Stream& s : streams)
-      if (bp_submit_bam(s.h, p.data, p.bytes, p.off.data(), (int64_t)p.off.size()) != BP_OK) return HandleErr(s.h);
+    Stream& s = streams[stream];
+    if (bp_submit_bam(s.h, p.data, p.bytes, p.off.data(), (int64_t)p.off.size()) != BP_OK) return HandleErr(s.h);
     return "";
   }
 
@@ -405,10 +405,11 @@ class Closer {
 };
 
 // The open job's pieces go to the device (bp_submit_bam: host scan, copy, pack kernel) on a
-// thread of their own, in order, while the main thread walks the next chunk.
+// thread of their own, in order, while the main thread walks the next chunk.  One submitter per
+// output stream (-per-strand has two handles a job, fed the same pieces side by side).
 class Submitter {
  public:
-  explicit Submitter(Driver* d) : drv_(d), th_([this] { Run(); }) {}
+  Submitter(Driver* d, size_t stream) : drv_(d), stream_(stream), th_([this] { Run(); }) {}
   ~Submitter() {
     {
       std::unique_lock<std::mutex> lk(mu_);
@@ -449,7 +450,7 @@ class Submitter {
         cv_.notify_all();
       }
       const double t0 = Now();
-      std::string e = drv_->SubmitPiece(p);
+      std::string e = drv_->SubmitPiece(stream_, p);
       p = Piece();  // the chunk's buffer goes back to the reader's pool
       busy_s_ += Now() - t0;
       std::unique_lock<std::mutex> lk(mu_);
@@ -462,6 +463,7 @@ class Submitter {
     }
   }
   Driver* drv_;
+  size_t stream_;
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<Piece> q_;
@@ -656,13 +658,31 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   CloseGate gate;
   std::vector<std::unique_ptr<Closer>> closers;
   for (size_t k = 0; k < drv.n_closers(); k++) closers.emplace_back(new Closer(&drv, &gate));
-  Submitter submitter(&drv);
+  std::vector<std::unique_ptr<Submitter>> submitters;
+  for (size_t k = 0; k < drv.streams.size(); k++) submitters.emplace_back(new Submitter(&drv, k));
+  auto push_piece = [&](Piece&& p) -> std::string {
+    std::string e;
+    for (size_t k = 0; k + 1 < submitters.size(); k++) {
+      std::string ek = submitters[k]->Push(Piece(p));
+      if (e.empty()) e = ek;
+    }
+    std::string el = submitters.back()->Push(std::move(p));
+    return e.empty() ? el : e;
+  };
+  auto drain = [&]() -> std::string {
+    std::string e;
+    for (auto& sm : submitters) {
+      std::string ek = sm->Drain();
+      if (e.empty()) e = ek;
+    }
+    return e;
+  };
   auto open_job = [&]() -> std::string {
     std::string e = drv.OpenJob(jobs[ji]);
     open = e.empty();
     // what the job was given while the ones before it were open
     for (Piece& p : pend[0])
-      if (e.empty()) e = submitter.Push(std::move(p));
+      if (e.empty()) e = push_piece(std::move(p));
     pend[0].clear();
     return e;
   };
@@ -679,7 +699,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
       p.off.swap(sel[k]);
       while (pend.size() <= k) pend.emplace_back();
       if (k == 0 && open) {
-        if (e.empty()) e = submitter.Push(std::move(p));
+        if (e.empty()) e = push_piece(std::move(p));
       } else {
         pend[k].push_back(std::move(p));
       }
@@ -691,7 +711,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (!sel.empty()) sel.erase(sel.begin());
     if (sel.empty()) sel.emplace_back();
     double t0 = Now();
-    if (e.empty()) e = submitter.Drain();
+    if (e.empty()) e = drain();
     st.submit_s += Now() - t0;
     t0 = Now();
     if (e.empty()) e = closers[ji % closers.size()]->Push(jobs[ji], drv.TakeHandles(), drv.open_rows);
@@ -860,7 +880,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   }
   {
     const double t0 = Now();
-    (void)submitter.Drain();
+    (void)drain();
     for (auto& c : closers) c->Join();
     st.close_wait_s += Now() - t0;
     for (auto& c : closers) st.close_s += c->busy_s();
@@ -881,7 +901,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
             "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
             "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) total_s=%.3f\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
-            index.loaded() ? 1 : 0, submitter.busy_s(), st.submit_s, st.close_s, st.close_wait_s,
+            index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, st.close_wait_s,
             st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), st.total_s);
   return "";
 }

@@ -778,27 +778,34 @@ __device__ __forceinline__ bool next_m_op(const uint32_t* cg, uint32_t cg0, uint
 __device__ __forceinline__ bool next_piece(const uint32_t* cg, uint32_t cg0, uint32_t cg1, uint32_t cg2,
                                            uint32_t n_cigar, uint32_t wlen, uint32_t& c, int32_t& r, int32_t& q,
                                            int32_t& rs, int32_t& rl, int32_t& rq, const uint32_t* mcg,
-                                           uint32_t mn, int32_t mrel, int32_t& sref, int32_t& slen,
+                                           const u32x4a& m4, uint32_t mn, int32_t mrel, int32_t& sref, int32_t& slen,
                                            int32_t& sq0, int32_t& ms, int32_t& ml, int32_t& mq0) {
   if (rl == 0 && !next_m_op(cg, cg0, cg1, cg2, n_cigar, wlen, c, r, q, rs, rl, rq)) return false;
   int32_t mr = mrel, mq = 0, nxt = 0x7fffffff;
   bool found = false;
   ms = 0; ml = 0; mq0 = 0;
-  for (uint32_t k = 0; k < mn; k++) {
-    const uint32_t cop = mcg[k];
+  // the mate's first four ops came in one load (a load per op is a chain of round trips, and the
+  // walk starts over for every piece); longer CIGARs go on from memory
+  bool done = false;
+  auto step = [&](uint32_t cop) {
     const uint32_t op = cop & 15u;
     const int32_t len = (int32_t)(cop >> 4);
     if (op == 0) {
-      if (found) { nxt = mr; break; }
+      if (found) { nxt = mr; done = true; return; }
       if (mr + len > rs) { found = true; ms = mr; ml = len; mq0 = mq; }
       mr += len;
       mq += len;
     } else {
       mq += (op == 1 || op == 4) ? len : 0;
       mr += (op == 2 || op == 3) ? len : 0;
-      if (op > 5) break;
+      if (op > 5) done = true;
     }
-  }
+  };
+  if (mn > 0) step(m4.x);
+  if (!done && mn > 1) step(m4.y);
+  if (!done && mn > 2) step(m4.z);
+  if (!done && mn > 3) step(m4.w);
+  for (uint32_t k = 4; k < mn && !done; k++) step(mcg[k]);
   const int32_t e = rs + rl, cut = nxt < e ? nxt : e;  // nxt > rs: it lies past an M op that ends after rs
   sref = rs;
   slen = cut - rs;
@@ -1102,19 +1109,19 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           if (pieces) {
             const uint32_t* mcg = (const uint32_t*)(P.blob + (uint64_t)minfo.z * 8);
             const uint32_t mn = minfo.w >> 16;
+            const u32x4a m4 = *(const u32x4a*)mcg;  // (past a short CIGAR this reads into the mate's bases: unused)
             uint32_t c = c_cur;
             int32_t r_ = rr, q_ = qq, rs = rem_s, rl = rem_l, rq = rem_q;
-            int32_t sA = 0, lA = 0, qA = 0, sB = 0, lB = 0, qB = 0;
-            int32_t msA = 0, mlA = 0, mqA = 0, msB = 0, mlB = 0, mqB = 0;
-            wantA = next_piece(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, rs, rl, rq, mcg, mn, (int32_t)minfo.x,
+            int32_t sA = 0, lA = 0, qA = 0;
+            int32_t msA = 0, mlA = 0, mqA = 0;
+            // One piece per admission step (the other paths take two M ops): a second walk's
+            // results would have to live next to the first's, and this path is what decides the
+            // stitched variants' register count (with two: 16 VGPRs spilled once the mate's ops
+            // are held in registers).
+            wantA = next_piece(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, rs, rl, rq, mcg, m4, mn, (int32_t)minfo.x,
                                sA, lA, qA, msA, mlA, mqA);
-            if (wantA)
-              wantB = next_piece(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, rs, rl, rq, mcg, mn, (int32_t)minfo.x,
-                                 sB, lB, qB, msB, mlB, mqB);
             A.sref = sA; A.len = lA; A.q0 = qA;
-            B.sref = sB; B.len = lB; B.q0 = qB;
             miA.x = (uint32_t)msA; miA.y = (minfo.y & 0xffff0000u) | (uint32_t)mlA; mxA = mqd | (uint32_t)mqA;
-            miB.x = (uint32_t)msB; miB.y = (minfo.y & 0xffff0000u) | (uint32_t)mlB; mxB = mqd | (uint32_t)mqB;
             cB = c; rrB = r_; qqB = q_;
             rsB = rs; rlB = rl; rqB = rq;
             if (!wantA) more = false;

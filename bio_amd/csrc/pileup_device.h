@@ -133,6 +133,7 @@ struct KernelParams {
   // options (bp_opts)
   int32_t clip, flag_exclude, mapq, min_base_qual, stitch, ignore_strand, strand_req;
   int32_t qpass;              // the payloads carry pass bits (see the payload layout)
+  int32_t wins_per_block;     // consecutive windows a workgroup of pileup_kernel takes (set by launch_pileup)
 };
 
 // One entry of a per-read feature list = PerReadFeatures (pileup/snp/row.go:22-31), 6 bytes.

@@ -10,7 +10,7 @@
 //                         Depth + Counts[5][2] per BED position (pileup.go:518-570).
 //   column_sums_kernel    checksum of the rows.
 //
-// Mapping (wave64, 512-thread workgroups).  A workgroup owns kWinPerBlock consecutive
+// Mapping (wave64, 512-thread workgroups).  A workgroup owns up to kWinPerBlockMax consecutive
 // windows of kW reference positions and walks them one after the other:
 //   phase 1  thread = record.  Read-level filters, then the CIGAR walk turns every M op into
 //            a segment clipped to the window (two per lane per step); a wave hands out
@@ -79,7 +79,7 @@ namespace bp {
 #define BP_DEPTHQ 2
 #endif
 #ifndef BP_WINS
-#define BP_WINS 8
+#define BP_WINS 24   // at most; fewer when the job has too few windows to fill the device that way
 #endif
 #ifndef BP_FLUSH_UPPER
 #define BP_FLUSH_UPPER 8   // eighths of a window's positions flushed by the upper half of the waves
@@ -180,7 +180,7 @@ template <bool EXTRA> constexpr int seg_cap() { return EXTRA ? kSegCapExtra : kS
 constexpr int kUnitCap = BP_UNITCAP; // units (32 window positions of one segment) per round
 constexpr int kDepth = BP_DEPTH;     // units in flight per lane (software pipeline depth)
 constexpr int kDepthQ = BP_DEPTHQ;   // ... when the quals are loaded too
-constexpr int kWinPerBlock = BP_WINS; // consecutive windows per workgroup
+constexpr int kWinPerBlockMax = BP_WINS; // consecutive windows per workgroup (KernelParams::wins_per_block)
 
 // LDS histogram: 12 counter planes (A+ A- C+ C- G+ G- T+ T- X+ X- lowq+ lowq-), each plane
 // laid out by residue: position p = 32j + r lives at r*kSub + j.
@@ -836,7 +836,7 @@ __device__ __forceinline__ Window uni_window(const Window& v) {
   return w;
 }
 
-// Workgroup = kWinPerBlock consecutive windows, processed one after the other:
+// Workgroup = KernelParams::wins_per_block consecutive windows, processed one after the other:
 //   phase 1  thread = record: read filters, CIGAR -> M-segments clipped to the window
 //   phase 2  thread = unit:   counts into the LDS planes
 //   flush    thread = position: Depth + Counts row to HBM, planes zeroed on the way out
@@ -867,8 +867,8 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   const uint32_t xcd = blockIdx.x & 7u, slot8 = blockIdx.x >> 3;
   const uint32_t q8 = nwg >> 3, r8 = nwg & 7u;
   const uint32_t blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
-  uint32_t w_first = blk * kWinPerBlock;
-  uint32_t w_last = w_first + kWinPerBlock;
+  uint32_t w_first = blk * (uint32_t)P.wins_per_block;
+  uint32_t w_last = w_first + (uint32_t)P.wins_per_block;
   if (w_last > (uint32_t)P.n_windows) w_last = (uint32_t)P.n_windows;
   if constexpr (DEEP) {  // here `item` walks the extra items, one block stride apart
     w_first = blockIdx.x;
@@ -2053,9 +2053,14 @@ static void launch_pileup_variant(const KernelParams& P, dim3 g, hipStream_t s) 
 
 void launch_pileup(const KernelParams& P, hipStream_t s) {
   if (P.n_windows == 0) return;
-  launch_pileup_variant<false>(P, dim3((P.n_windows + kWinPerBlock - 1) / kWinPerBlock), s);
+  // A workgroup's set-up (zeroing its LDS, priming the window prefetch) is shared by the windows it
+  // takes: 24 of them on a long contig (chr1 30x: 4.36 -> 4.31 ms, stitched 6.05 -> 6.00 ms against
+  // 8), fewer when that would leave less than ~4 workgroups per resident slot (512 on 256 CUs).
+  KernelParams Q = P;
+  Q.wins_per_block = std::max(1, std::min(kWinPerBlockMax, P.n_windows / 2048));
+  launch_pileup_variant<false>(Q, dim3((unsigned)((P.n_windows + Q.wins_per_block - 1) / Q.wins_per_block)), s);
   // extra slices of deep windows; blocks beyond the item count (read on the device) exit at once
-  if (P.extra_items) launch_pileup_variant<true>(P, dim3((unsigned)std::min(P.extra_cap, 2048)), s);
+  if (P.extra_items) launch_pileup_variant<true>(Q, dim3((unsigned)std::min(P.extra_cap, 2048)), s);
 }
 
 __global__ void rows_add_kernel(uint32_t* rows, const uint32_t* src, int64_t n) {

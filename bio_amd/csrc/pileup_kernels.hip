@@ -1078,6 +1078,11 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       // round's first barrier, and phase 1 touches nothing the flush still reads)
       BP_STAMP(1);
       // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
+      // (Wave priority: the two workgroups of a CU are in different phases most of the time.
+      // The stitched variant's phase 1 is its long serial part - mate lookup, piece walk - and
+      // goes first, 6.02 -> 5.96 ms on chr1 30x; without stitching the unit pass goes first,
+      // 4.32 -> 4.30 ms; the other way round each is slower.)
+      __builtin_amdgcn_s_setprio(STITCH ? 3 : 0);
       const bool has_rec = rec < r1;
       if (has_rec && !have) {
         uint4 c0 = pc0, c1 = pc1, me = pme;
@@ -1228,6 +1233,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
 
       // ---- phase 2: thread = unit (32 window positions of one segment); kDepth units in
       // flight per lane
+      __builtin_amdgcn_s_setprio(STITCH ? 0 : 3);
       if (tid == 0) {  // next round's counter and flag; next touched after the barrier below
         S.n_alloc[par ^ 1u] = 0;
         S.more[par ^ 1u] = 0;

@@ -108,6 +108,23 @@ def test_c1_shape_1mb_30x(mode):
     assert want[2][:, 0].sum() > 10e6  # the case is not vacuous
 
 
+@pytest.mark.parametrize("mode", ["basestrand", "stitch"])
+@pytest.mark.parametrize("n_windows", [2 * 2048 + 5, 5 * 2048 + 3])
+def test_windows_per_workgroup_in_between(n_windows, mode):
+    """A workgroup takes n_windows / 2048 consecutive windows, capped at 24 (launch_pileup): the
+    small cases above run with 1, the full-size ones with 24; here 2 and 5, with a last workgroup
+    that gets fewer windows than the others.  Whole rows against the oracle."""
+    kw = dict(basestrand=dict(), stitch=dict(stitch=1, min_base_qual=20))[mode]
+    opts = O.make_opts(**kw)
+    L = n_windows * 1024 - 300
+    bed = {0: [[0, L]]}
+    got, want, sb = _synth_case([(0, 0, L - 1000, 4.0)], bed, [L], opts, with_names=True)
+    assert len(want[1]) == L
+    assert_same(got, want, f"{n_windows} windows {mode}")
+    assert want[2][:, 0].sum() > 10e6
+    sb.close()
+
+
 def test_c1_region_mode_no_halo():
     """-region semantics: a single unpadded shard (pileup.go:1091-1097)."""
     opts = O.make_opts()

@@ -1507,7 +1507,10 @@ struct PrChunk {
 template <bool CLIP>
 __global__ __launch_bounds__(kPrBlock) void per_read_kernel(KernelParams P, PerReadParams Q) {
   extern __shared__ __align__(16) uint8_t pr_lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // wave-uniform by construction, and told so: the tile's interval, rows, offsets and record range
+  // are then worked out on the scalar unit and held in SGPRs (95 -> 82 VGPRs, 36.9 -> 35.2 ms)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // consecutive workgroups go to different XCDs, each with its own L2: give every XCD a
   // contiguous run of tiles, so that the records neighbouring tiles share come from one L2
   const uint32_t per_xcd = gridDim.x >> 3;  // the launcher rounds the grid up to a multiple of 8

@@ -79,6 +79,7 @@ HOST_EXPORTS = [
     "bio_pileup_write_rows", "bio_pileup_row_fields", "bio_marshal_pileup_row", "bio_unmarshal_pileup_row",
     "bio_marshal_basestrand", "bio_unmarshal_basestrand", "bio_basestrand_rio_trailer",
     "bio_parse_basestrand_rio_trailer", "bio_basestrand_piles_to_tsv",
+    "bio_read_basestrand_tsv", "bio_read_single_strand_basestrand_tsv", "bio_chr_id",
 ]
 
 
@@ -104,6 +105,11 @@ class bio_pileup_opts(C.Structure):
         ("device", C.c_int32),
         ("devices", C.c_int32),
     ]
+
+
+class bio_basestrand_tsv_row(C.Structure):
+    """include/bio_pileup_host.h: BaseStrandTsvRow"""
+    _fields_ = [("chr", C.c_char * 64), ("pos", C.c_int64), ("ref", C.c_char * 8), ("counts", C.c_int64 * 8)]
 
 
 _lib = None
@@ -245,5 +251,12 @@ def load():
     lib.bio_basestrand_piles_to_tsv.argtypes = [C.c_int64, i32p, i32p, u32p, C.c_int32, C.POINTER(C.c_char_p),
                                                 C.c_char_p, C.c_void_p, C.c_size_t]
     lib.bio_basestrand_piles_to_tsv.restype = C.c_int64
+    rowp = C.POINTER(bio_basestrand_tsv_row)
+    lib.bio_read_basestrand_tsv.argtypes = [C.c_char_p, C.c_size_t, rowp, C.c_int64] + E
+    lib.bio_read_basestrand_tsv.restype = C.c_int64
+    lib.bio_read_single_strand_basestrand_tsv.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, rowp, C.c_int64] + E
+    lib.bio_read_single_strand_basestrand_tsv.restype = C.c_int64
+    lib.bio_chr_id.argtypes = [C.c_char_p, C.POINTER(C.c_int32)] + E
+    lib.bio_chr_id.restype = C.c_int
     _lib = lib
     return lib

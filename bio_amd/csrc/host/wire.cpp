@@ -4,9 +4,11 @@
 //   marshalBaseStrand / UnmarshalBaseStrand  pileup/snp/basestrand.go:103-135, :183-201
 //   baseStrandsRioTrailer / parse...Trailer  pileup/snp/basestrand.go:77-101
 //   WriteBaseStrandToTSV, WriteBaseStrandTsv pileup/snp/basestrand.go:204-231, :282-290
+//   ReadBaseStrandTsv, ReadSingleStrandBaseStrandTsv, ChrId   basestrand.go:262-279, :309-367, :401-422
 // All little-endian, plain host code; declared in include/bio_pileup_host.h.
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../../include/bio_pileup_host.h"
 
@@ -33,9 +35,183 @@ void AppendUint(std::string& s, uint64_t v) {
   s.append(t + n, (size_t)(24 - n));
 }
 
+// ---- the TSV readers of basestrand.go.  grailbio/base's tsv.Reader (absent from the tree) is a
+// csv.Reader with Comma '\t': empty lines are skipped, a line starting with the Comment byte is
+// skipped, a trailing '\r' is dropped, and integer columns go through strconv.ParseInt, whose
+// error text ("strconv.ParseInt: parsing \"A\": invalid syntax") the reference's test looks for.
+
+int SetErr(char* err, size_t errlen, const std::string& m) {
+  if (err && errlen) { size_t k = m.size() < errlen - 1 ? m.size() : errlen - 1; memcpy(err, m.data(), k); err[k] = 0; }
+  return -1;
+}
+
+struct TsvLines {
+  const char* p;
+  const char* end;
+  char comment;  // 0: none
+  // next non-empty, non-comment line as fields (views into the text); false at the end
+  bool Next(std::vector<std::pair<const char*, size_t>>& f) {
+    while (p < end) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+      const char* le = nl ? nl : end;
+      const char* b = p;
+      p = nl ? nl + 1 : end;
+      if (le > b && le[-1] == '\r') le--;
+      if (le == b) continue;
+      if (comment && *b == comment) continue;
+      f.clear();
+      for (;;) {
+        const char* t = (const char*)memchr(b, '\t', (size_t)(le - b));
+        const char* fe = t ? t : le;
+        f.emplace_back(b, (size_t)(fe - b));
+        if (!t) break;
+        b = t + 1;
+      }
+      return true;
+    }
+    return false;
+  }
+};
+
+// strconv.ParseInt(s, 10, 64) with its error wording
+bool ParseInt64(const char* s, size_t n, int64_t* out, std::string* why) {
+  auto bad = [&](const char* what) {
+    *why = "strconv.ParseInt: parsing \"" + std::string(s, n) + "\": " + what;
+    return false;
+  };
+  size_t i = 0;
+  bool neg = false;
+  if (n && (s[0] == '+' || s[0] == '-')) { neg = s[0] == '-'; i = 1; }
+  if (i == n) return bad("invalid syntax");
+  uint64_t v = 0;
+  const uint64_t lim = neg ? (uint64_t)1 << 63 : ((uint64_t)1 << 63) - 1;
+  for (; i < n; i++) {
+    if (s[i] < '0' || s[i] > '9') return bad("invalid syntax");
+    const uint64_t d = (uint64_t)(s[i] - '0');
+    if (v > (lim - d) / 10) return bad("value out of range");
+    v = v * 10 + d;
+  }
+  *out = neg ? (int64_t)(0 - v) : (int64_t)v;
+  return true;
+}
+
+bool PutStr(char* dst, size_t cap, const char* s, size_t n) {
+  if (n >= cap) return false;
+  memcpy(dst, s, n);
+  memset(dst + n, 0, cap - n);
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t bio_read_basestrand_tsv(const char* text, size_t len, bio_basestrand_tsv_row* rows, int64_t cap, char* err,
+                                size_t errlen) {
+  // ReadBaseStrandTsv (basestrand.go:262-279): no header row is declared, Comment = '#' hides the
+  // "#CHROM ..." line, columns map to BaseStrandTsvRow's fields by position
+  if (!text && len) return SetErr(err, errlen, "bio_read_basestrand_tsv: null text");
+  TsvLines L{text, text + len, '#'};
+  std::vector<std::pair<const char*, size_t>> f;
+  int64_t n = 0;
+  std::string why;
+  while (L.Next(f)) {
+    if (f.size() != 11) return SetErr(err, errlen, "record on line " + std::to_string((long long)n + 1) + ": wrong number of fields");
+    bio_basestrand_tsv_row r;
+    if (!PutStr(r.chr, sizeof r.chr, f[0].first, f[0].second) || !PutStr(r.ref, sizeof r.ref, f[2].first, f[2].second))
+      return SetErr(err, errlen, "bio_read_basestrand_tsv: CHROM or REF longer than the row holds");
+    if (!ParseInt64(f[1].first, f[1].second, &r.pos, &why)) return SetErr(err, errlen, why);
+    for (int k = 0; k < 8; k++)
+      if (!ParseInt64(f[3 + k].first, f[3 + k].second, &r.counts[k], &why)) return SetErr(err, errlen, why);
+    if (rows && n < cap) rows[n] = r;
+    n++;
+  }
+  if (err && errlen) err[0] = 0;
+  return n;
+}
+
+int64_t bio_read_single_strand_basestrand_tsv(const char* fwd, size_t fwd_len, const char* rev, size_t rev_len,
+                                              bio_basestrand_tsv_row* rows, int64_t cap, char* err, size_t errlen) {
+  // ReadSingleStrandBaseStrandTsv (basestrand.go:309-367): both files have a header row and the
+  // columns of singleStrandBaseStrandTsvRow (:293-305) are found by NAME; rows are read in
+  // lockstep until either file ends; CHROM/POS and REF must agree
+  static const char* const kCols[11] = {"CHROM", "POS", "DEPTH", "REF", "A", "C", "G", "T", "N", "INS", "DEL"};
+  struct Side {
+    TsvLines L;
+    int col[11];
+    std::vector<std::pair<const char*, size_t>> f;
+    std::string chr, ref;
+    int64_t v[11];
+  } S[2] = {{{fwd, fwd + fwd_len, 0}, {}, {}, {}, {}, {}}, {{rev, rev + rev_len, 0}, {}, {}, {}, {}, {}}};
+  if ((!fwd && fwd_len) || (!rev && rev_len)) return SetErr(err, errlen, "bio_read_single_strand_basestrand_tsv: null text");
+  bool has_header[2];
+  for (int s = 0; s < 2; s++) {
+    has_header[s] = S[s].L.Next(S[s].f);
+    if (!has_header[s]) continue;  // an empty file: EOF at the first Read, no rows
+    for (int c = 0; c < 11; c++) {
+      S[s].col[c] = -1;
+      for (size_t j = 0; j < S[s].f.size(); j++)
+        if (S[s].f[j].second == strlen(kCols[c]) && !memcmp(S[s].f[j].first, kCols[c], S[s].f[j].second)) { S[s].col[c] = (int)j; break; }
+      if (S[s].col[c] < 0) return SetErr(err, errlen, std::string("column ") + kCols[c] + " does not appear in the header");
+    }
+  }
+  int64_t n = 0;
+  std::string why;
+  for (;;) {
+    bool eof = false;
+    for (int s = 0; s < 2 && !eof; s++) {
+      Side& d = S[s];
+      if (!has_header[s] || !d.L.Next(d.f)) { eof = true; break; }
+      const size_t ncol = d.f.size();
+      for (int c = 0; c < 11; c++) {
+        if ((size_t)d.col[c] >= ncol) return SetErr(err, errlen, "record on line " + std::to_string((long long)n + 2) + ": wrong number of fields");
+        const auto& x = d.f[(size_t)d.col[c]];
+        if (c == 0) d.chr.assign(x.first, x.second);
+        else if (c == 3) d.ref.assign(x.first, x.second);
+        else if (!ParseInt64(x.first, x.second, &d.v[c], &why)) return SetErr(err, errlen, why);
+      }
+    }
+    if (eof) break;
+    if (S[0].chr != S[1].chr || S[0].v[1] != S[1].v[1])
+      return SetErr(err, errlen, "expected equal chromosome position but got fwd: " + S[0].chr + " " + std::to_string((long long)S[0].v[1]) +
+                                     " and rev: " + S[1].chr + " " + std::to_string((long long)S[1].v[1]));
+    if (S[0].ref != S[1].ref)
+      return SetErr(err, errlen, "expected equal reference alleles but got fwd: " + S[0].ref + " and rev: " + S[1].ref);
+    bio_basestrand_tsv_row r;
+    if (!PutStr(r.chr, sizeof r.chr, S[0].chr.data(), S[0].chr.size()) || !PutStr(r.ref, sizeof r.ref, S[0].ref.data(), S[0].ref.size()))
+      return SetErr(err, errlen, "bio_read_single_strand_basestrand_tsv: CHROM or REF longer than the row holds");
+    r.pos = S[0].v[1];
+    for (int b = 0; b < 4; b++) { r.counts[2 * b] = S[0].v[4 + b]; r.counts[2 * b + 1] = S[1].v[4 + b]; }
+    if (rows && n < cap) rows[n] = r;
+    n++;
+  }
+  if (err && errlen) err[0] = 0;
+  return n;
+}
+
+int bio_chr_id(const char* chr, int32_t* id, char* err, size_t errlen) {
+  // ChrId (basestrand.go:401-422): the name behind its 3-byte "chr" prefix (whatever those bytes
+  // are: the reference slices chr[3:] without looking, and panics on a shorter string)
+  if (!chr || strlen(chr) < 3) return SetErr(err, errlen, "ChrId: name shorter than its \"chr\" prefix");
+  const std::string t(chr + 3);
+  int v = 0;
+  if (t == "X") v = 23;
+  else if (t == "Y") v = 24;
+  else if (t == "M") v = 25;
+  else {
+    int64_t i = 0;
+    std::string why;
+    if (!ParseInt64(t.data(), t.size(), &i, &why)) {
+      const bool range = why.find("out of range") != std::string::npos;
+      return SetErr(err, errlen, "strconv.Atoi: parsing \"" + t + "\": " + (range ? "value out of range" : "invalid syntax"));
+    }
+    if (i <= 0 || i >= 23) return SetErr(err, errlen, std::to_string((long long)i) + " is not a valid chromosome id");
+    v = (int)i;
+  }
+  if (id) *id = v;
+  if (err && errlen) err[0] = 0;
+  return 0;
+}
 
 uint32_t bio_pileup_row_fields(const uint32_t* vals, const uint32_t list_len[4], int32_t per_read_needed) {
   // flushToInternal (pileup.go:518-570): a zero-depth row carries no field; otherwise the

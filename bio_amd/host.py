@@ -280,3 +280,37 @@ def basestrand_piles_to_tsv(ref_id, pos, counts8, ref_names, ref_bases=None):
     out = C.create_string_buffer(int(n) + 1)
     lib.bio_basestrand_piles_to_tsv(*args, out, n)
     return out.raw[:n]
+
+
+def _tsv_rows(call, *texts):
+    lib = _abi.load()
+    e = _err()
+    args = []
+    for t in texts:
+        args += [t, len(t)]
+    n = call(lib)(*args, None, 0, e, len(e))
+    if n < 0:
+        raise ValueError(e.value.decode())
+    rows = (_abi.bio_basestrand_tsv_row * max(int(n), 1))()
+    call(lib)(*args, rows, n, e, len(e))
+    keys = ("FwdA", "RevA", "FwdC", "RevC", "FwdG", "RevG", "FwdT", "RevT")
+    return [dict(Chr=r.chr.decode(), Pos=r.pos, Ref=r.ref.decode(), **dict(zip(keys, r.counts))) for r in rows[:n]]
+
+
+def read_basestrand_tsv(text):
+    """ReadBaseStrandTsv (basestrand.go:262-279) -> list of BaseStrandTsvRow dicts"""
+    return _tsv_rows(lambda lib: lib.bio_read_basestrand_tsv, bytes(text))
+
+
+def read_single_strand_basestrand_tsv(fwd, rev):
+    """ReadSingleStrandBaseStrandTsv (basestrand.go:309-367)"""
+    return _tsv_rows(lambda lib: lib.bio_read_single_strand_basestrand_tsv, bytes(fwd), bytes(rev))
+
+
+def chr_id(name):
+    """ChrId (basestrand.go:401-422)"""
+    lib = _abi.load()
+    v, e = C.c_int32(), _err()
+    if lib.bio_chr_id(name.encode(), C.byref(v), e, len(e)):
+        raise ValueError(e.value.decode())
+    return v.value

@@ -155,6 +155,33 @@ int64_t bio_basestrand_piles_to_tsv(int64_t n, const int32_t* ref_id, const int3
                                     int32_t n_ref, const char* const* ref_names, const char* ref_bases, char* out,
                                     size_t cap);
 
+
+/* ---- readers of the output (the exported consumers of basestrand files) */
+
+/* BaseStrandTsvRow (pileup/snp/basestrand.go:247-259).  counts = FwdA RevA FwdC RevC FwdG RevG
+ * FwdT RevT, the file's column order; chr and ref are NUL-terminated. */
+typedef struct bio_basestrand_tsv_row {
+  char chr[64];
+  int64_t pos;
+  char ref[8];
+  int64_t counts[8];
+} bio_basestrand_tsv_row;
+
+/* ReadBaseStrandTsv (basestrand.go:262-279) over a file's text in memory: lines starting with
+ * '#' are comments (that hides the header), columns map to the row's fields by position.
+ * Returns the number of rows (the first cap of them are written; rows NULL: count only) or -1
+ * with strconv's wording in err ("... invalid syntax") for a column that is no integer. */
+int64_t bio_read_basestrand_tsv(const char* text, size_t len, bio_basestrand_tsv_row* rows, int64_t cap, char* err,
+                                size_t errlen);
+/* ReadSingleStrandBaseStrandTsv (basestrand.go:309-367): the forward- and reverse-strand files
+ * (header row CHROM POS DEPTH REF A C G T N INS DEL, columns found by name) read in lockstep
+ * into one row per position: Fwd* from the first, Rev* from the second; CHROM/POS and REF must
+ * agree (the reference's two error texts). */
+int64_t bio_read_single_strand_basestrand_tsv(const char* fwd, size_t fwd_len, const char* rev, size_t rev_len,
+                                              bio_basestrand_tsv_row* rows, int64_t cap, char* err, size_t errlen);
+/* ChrId (basestrand.go:401-422): "chr1".."chr22" -> 1..22, chrX 23, chrY 24, chrM 25. */
+int bio_chr_id(const char* chr, int32_t* id, char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

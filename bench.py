@@ -224,6 +224,7 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
                 raise SystemExit("e2e: device rows differ from the CPU oracle's rows from the decoded sample BAM")
             cpu_B = kept_aligned_bases(srb, opts_kw, [[0, sample_bp]])
             blk["cpu"] = {"value": round(cpu_B / cpu_s / 1e9, 4), "unit": "Gbase/s", "cores": 1, "kind": "port",
+                          "cpu_model": cpu_model(), "nproc": os.cpu_count(),
                           "sample": f"first {sample_bp / 1e6:.0f} Mb ({hi} records, {os.path.getsize(sbam) / 1e9:.2f} GB BAM): "
                                     f"BGZF inflate + record decode (oracle/bam_decode.c, zlib) {dec_s:.1f} s, then rows "
                                     f"(oracle/pileup_oracle.c) - {cpu_s:.1f} s in all, 1 thread, no text output"}
@@ -232,11 +233,29 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def c3_share(rank, world):
-    """Position ranges of rank `rank` when the 24 contigs are cut into `world` runs of equal size."""
-    from bio_amd import partition
-    bed = {r: [[0, l]] for r, l in enumerate(HG38_LENS)}
-    return partition.plan_partitions(bed, world)[rank]
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child
+    processes (torch.distributed.run, one rank per GPU) BEFORE this process makes any GPU call,
+    pass their output through and leave with their exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -258,14 +277,18 @@ def main():
     cname = args.config
     coverage = args.coverage if args.coverage is not None else cfg["coverage"]
 
+    emulate = os.environ.get("BENCH_EMULATE_RANK")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not emulate:
+        self_launch(args.gpus)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    emulate = os.environ.get("BENCH_EMULATE_RANK")
     if world != args.gpus and not (emulate and world == 1):
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with torch.distributed.run "
-                         f"(one rank per GPU), or set BENCH_EMULATE_RANK=g/N to run one rank's share alone")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree "
+                         f"(leave WORLD_SIZE unset and bench.py starts its own ranks; BENCH_EMULATE_RANK=g/N runs one "
+                         f"rank's share alone)")
     if world > 1 and cname not in ("c2", "c3"):
         raise SystemExit(f"--config {cname} is a one-GPU workload")
     if not torch.cuda.is_available():
@@ -317,19 +340,14 @@ def main():
         # rows that belong to the next rank (when that rank continues the same contig).
         if pworld < 4:
             raise SystemExit("--config c3 (3.1 Gb at 30x) needs --gpus >= 4: a rank's share must fit one GPU and one job's 32 GiB of payload")
-        share = c3_share(prank, pworld)
-        nxt = c3_share(prank + 1, pworld)[0] if prank + 1 < pworld else None
-        last_ref, _, last_end = share[-1]
-        spill = nxt is not None and nxt[0] == last_ref  # the next rank continues this contig
-        regions = [(r, s, (e if (r, e) == (last_ref, last_end) and spill else e - 1000), coverage) for r, s, e in share]
-        bed = {}
-        for r, s, e in share:
-            bed.setdefault(r, []).append([s, e])
-        tail_rows = 0
-        if spill:
-            tail_rows = min(tail, HG38_LENS[last_ref] - last_end)
-            bed[last_ref][-1][1] = last_end + tail_rows
-        own_rows = sum(e - s for _, s, e in share)
+        share = partition.boundary_share({r: [[0, l]] for r, l in enumerate(HG38_LENS)}, pworld, prank, tail)
+        last = share["ranges"][-1]
+        # reads are generated up to the end of a range that the next rank continues, and stop
+        # 1,000 positions short of a contig's end
+        regions = [(r, s, (e if (r, s, e) == last and share["spill"] else e - 1000), coverage) for r, s, e in share["ranges"]]
+        bed = share["bed"]
+        tail_rows = share["tail_rows"]
+        own_rows = share["own_rows"]
         ref_lens = list(HG38_LENS)
         ref_names = [f"chr{i + 1}" for i in range(22)] + ["chrX", "chrY"]
         total_len = sum(HG38_LENS)
@@ -469,6 +487,7 @@ def main():
             if not ((doff == woff[:4 * n_cmp + 1]).all() and dfeat.tobytes() == wfeat[:int(woff[4 * n_cmp])].tobytes()):
                 raise SystemExit("device per-read lists differ from the CPU oracle on the baseline sample")
         cpu = {"value": round(cpu_B / cpu_s / 1e9, 4), "unit": "Gbase/s", "cores": 1, "kind": "port",
+               "cpu_model": cpu_model(), "nproc": os.cpu_count(),
                "sample": f"{what} of the same workload ({hi} records, {cpu_B} aligned bases on the sample's BED) in "
                          f"{cpu_s:.1f} s, records in memory -> rows{' + per-read lists' if per_read else ''}, same options, "
                          f"C restatement of the reference algorithm (oracle/pileup_oracle.c), 1 thread"}
@@ -476,24 +495,14 @@ def main():
         if cname == "c2":
             # the same restatement on all host cores of the box's share: independent position
             # ranges with a read halo, like the reference's jobs (pileup.go:862-932)
-            from concurrent.futures import ThreadPoolExecutor
             T = min(16, os.cpu_count() or 1)
-            edges = [L * i // T for i in range(T + 1)]
-
-            def one(i):
-                s, e = edges[i], edges[i + 1]
-                a = int(np.searchsorted(rb.pos, max(0, s - 1024), "left"))
-                b = int(np.searchsorted(rb.pos, e, "left"))
-                _, _, v = O.pileup(oopts, [L], {0: [[s, e]]}, rb.slice(a, b), parallelism=1)
-                return int(v[:, 0].sum())
-            tc = time.perf_counter()
-            with ThreadPoolExecutor(T) as ex:
-                mt_B = sum(ex.map(one, range(T)))
-            mt_s = time.perf_counter() - tc
-            if mt_B != B:
-                raise SystemExit(f"multi-threaded CPU run counted {mt_B} bases, expected {B}")
+            mt_sums, mt_s = O.whole_contig_column_sums(oopts, L, rb, T)
+            if mt_sums != sums:
+                raise SystemExit(f"column sums of the device rows {sums} != those of the CPU oracle's rows over the whole contig {mt_sums}")
+            mt_B = mt_sums[0]
             cpu["all_cores"] = {"value": round(mt_B / mt_s / 1e9, 4), "unit": "Gbase/s", "cores": T,
-                                "sample": f"the whole workload as {T} position ranges, one thread each, in {mt_s:.1f} s"}
+                                "sample": f"the whole workload as {T} position ranges, one thread each, in {mt_s:.1f} s; "
+                                          f"all 11 column sums of its rows equal the device's"}
 
     e2e = None
     if rank == 0 and pworld == 1 and not args.no_e2e and cname in ("c2", "c2q", "c2c", "c2s") and not emulate:

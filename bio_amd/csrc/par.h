@@ -8,6 +8,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstddef>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -23,6 +24,8 @@ class Pool {
 
   // f(i) for every i in [0, n), on at most `threads` threads of which the caller is one.
   // Returns when all calls have returned.  Callers on different threads may overlap.
+  // An exception thrown by f (on any thread) stops the hand-out of further indices and is
+  // rethrown on the caller once every helper has left the job: the job lives in this frame.
   template <class F>
   void Run(size_t n, int threads, F&& f) {
     if (n == 0) return;
@@ -35,6 +38,7 @@ class Pool {
     job.n = n;
     job.arg = &ctx;
     job.call = [](void* a, size_t i) { (*static_cast<Ctx*>(a)->f)(i); };
+    job.mu = &mu_;
     job.max_helpers = (int)std::min<size_t>((size_t)threads - 1, n - 1);
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -50,6 +54,7 @@ class Pool {
         if (jobs_[k] == &job) { jobs_.erase(jobs_.begin() + (ptrdiff_t)k); break; }
       done_cv_.wait(lk, [&] { return job.helpers == 0; });
     }
+    if (job.error) std::rethrow_exception(job.error);
   }
 
  private:
@@ -61,6 +66,8 @@ class Pool {
     int max_helpers = 0;
     int joined = 0;   // helpers that ever took the job (under mu_)
     int helpers = 0;  // helpers inside Work() now (under mu_)
+    std::exception_ptr error;  // the first exception f threw (under *mu)
+    std::mutex* mu = nullptr;
   };
   static constexpr int kMaxWorkers = 63;
 
@@ -68,7 +75,14 @@ class Pool {
     for (;;) {
       const size_t i = j->next.fetch_add(1, std::memory_order_relaxed);
       if (i >= j->n) return;
-      j->call(j->arg, i);
+      try {
+        j->call(j->arg, i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(*j->mu);
+        if (!j->error) j->error = std::current_exception();
+        j->next.store(j->n, std::memory_order_relaxed);  // hand out nothing more
+        return;
+      }
     }
   }
   void Grow(int want) {  // under mu_

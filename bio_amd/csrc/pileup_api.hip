@@ -882,7 +882,10 @@ int bp_init(int32_t device) {
   if (device < 0 || device >= n) return fail(nullptr, BP_EINVAL, "bp_init: device %d of %d", device, n);
   e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, BP_EDEVICE, "hipSetDevice: %s", hipGetErrorString(e));
-  return resolve_scratch(device);
+  // (a GPU whose scratch address cannot be found still serves every entry point but
+  // bp_compute_static, which then says so)
+  (void)resolve_scratch(device);
+  return BP_OK;
 }
 
 int bp_device_count(void) {
@@ -943,7 +946,10 @@ int bp_reserve(bp_handle* h, int64_t n_records, int64_t payload_bytes) {
   HIP_TRY(h, hipSetDevice(h->device));
   // payload grows by padding: cigar to even count, qual/seq to whole 8-base units
   if (h->o.stitch) h->mate.reserve((size_t)n_records);
-  size_t blob = (size_t)payload_bytes + (size_t)n_records * (h->qpass ? 48 : 16) + 4096;
+  // (and by one pass bit per base where the job has them: l_seq <= 2/3 of the payload, a dword of
+  // padding per record)
+  size_t blob = (size_t)payload_bytes + (size_t)n_records * 24 + 4096;
+  if (h->qpass) blob += (size_t)payload_bytes / 8 + (size_t)n_records * 8;
   if (int rc = ensure(h, h->d_cores, (size_t)n_records * sizeof(ReadCore) + 256, (size_t)h->n_reads * sizeof(ReadCore))) return rc;
   if (int rc = ensure(h, h->d_blob, blob, (size_t)h->blob_used * 8)) return rc;
   return BP_OK;
@@ -1227,6 +1233,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
                 }
                 bits = minq <= 2 ? (bits | cm) : (bits & ~cm);
               }
+              if (8 * j + 8 > l) bits &= (1u << (l - 8 * j)) - 1u;  // pad bits 0, as pack_records leaves them
               m[j] = (uint8_t)bits;
             }
           }
@@ -1257,6 +1264,18 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
   return BP_OK;
 }
 
+// Nothing may propagate out of an extern "C" entry point: an exception from the host passes (a
+// vector that cannot grow, on this thread or on a pool thread, par.h) ends the call with BP_ENOMEM.
+static int guarded_submit(bp_handle* h, const Src& S, const char* who) {
+  try {
+    return submit_records(h, S, who);
+  } catch (const std::bad_alloc&) {
+    return fail(h, BP_ENOMEM, "%s: out of host memory", who);
+  } catch (const std::exception& ex) {
+    return fail(h, BP_ENOMEM, "%s: %s", who, ex.what());
+  }
+}
+
 int bp_submit(bp_handle* h, const bp_record_batch* b) {
   if (!h || !b) return fail(h, BP_EINVAL, "bp_submit: null argument");
   Src S;
@@ -1270,12 +1289,13 @@ int bp_submit(bp_handle* h, const bp_record_batch* b) {
   S.n_cigar = b->n_cigar;
   S.l_seq = b->l_seq;
   S.b = b;
-  return submit_records(h, S, "bp_submit");
+  return guarded_submit(h, S, "bp_submit");
 }
 
 int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32_t* rec_off, int64_t n) {
   if (!h || n < 0 || (n > 0 && (!bam || !rec_off))) return fail(h, BP_EINVAL, "bp_submit_bam: bad argument");
   if (n_bytes > 0xffffffffull) return fail(h, BP_EINVAL, "bp_submit_bam: more than 4 GiB in one call");
+  try {
   // The fixed fields of every record (SAM spec 4.2; gbam.Unmarshal, encoding/bam/unmarshal.go:126-224)
   // into columns, on all packing threads; a record that does not fit its block, or the bytes
   // given, is refused before anything of the call is taken.
@@ -1343,7 +1363,12 @@ int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32
   S.rec_bytes = h->x_bytes.data();
   S.span = h->x_span.data();
   S.cig_facts = h->x_cfacts.data();
-  return submit_records(h, S, "bp_submit_bam");
+  return guarded_submit(h, S, "bp_submit_bam");
+  } catch (const std::bad_alloc&) {
+    return fail(h, BP_ENOMEM, "bp_submit_bam: out of host memory");
+  } catch (const std::exception& ex) {
+    return fail(h, BP_ENOMEM, "bp_submit_bam: %s", ex.what());
+  }
 }
 
 constexpr int32_t kSliceRecs = 2048;  // records per slice of a deep window
@@ -1482,8 +1507,14 @@ int bp_compute_static(bp_handle* h) {
   if (!h->resident)
     return fail(h, BP_EINVAL, "bp_compute_static: call bp_finish first (it uploads what the kernels read; "
                               "this call allocates and uploads nothing)");
-  if (h->device < 0 || h->device >= kMaxDevices || !g_scratch_ptr[h->device])
-    return fail(h, BP_EINVAL, "bp_compute_static: no scratch address for device %d", h->device);
+  uint8_t* sp = nullptr;
+  if (h->device >= 0 && h->device < kMaxDevices) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    sp = g_scratch_ptr[h->device];
+  }
+  if (!sp)
+    return fail(h, BP_EDEVICE, "bp_compute_static: no scratch address for device %d (hipGetSymbolAddress failed in bp_init, "
+                               "or the device ordinal is beyond %d)", h->device, kMaxDevices - 1);
   const int64_t n_win = (int64_t)h->windows.size(), n_items = item_capacity(h);
   if (n_win > kStaticMaxWindows)
     return fail(h, BP_EINVAL, "bp_compute_static: %lld windows of %d positions; the static scratch holds %lld "
@@ -1493,7 +1524,6 @@ int bp_compute_static(bp_handle* h) {
                               "scratch holds %lld (use bp_compute, or cut the job)", (long long)n_items,
                 (long long)h->n_reads, (long long)kStaticMaxItems);
   HIP_TRY(h, hipSetDevice(h->device));
-  uint8_t* const sp = g_scratch_ptr[h->device];
   KernelParams P{};
   fill_params(h, P);
   P.win_r0 = (const int32_t*)(sp + kStaticR0Off);

@@ -38,7 +38,7 @@ enum : uint8_t {
 //   base part   uint32 cigar[n_cigar rounded up to even]
 //               uint8  seq4[4*U]   packed 4-bit bases (BAM codes), first base of a byte in the
 //                                  LOW nibble (BAM has it in the high one); pad nibbles 0
-//               uint8  qpass[U]    only in jobs with a quality rule and no stitching: bit k of
+//               uint8  qpass[U]    in every job but min_base_qual 0 without stitching: bit k of
 //                                  byte j = base 8j+k passes it, i.e. its quality, after clipQuals
 //                                  (pileup_support.go:51-69), is >= min_base_qual (addBase,
 //                                  pileup.go:227).  Both are job options, so the packer can say

@@ -122,6 +122,58 @@ def boundary_ranges(total_len, world_size, rank, tail):
     return start, end, min(end + tail, total_len)
 
 
+def boundary_share(bed, world_size, rank, tail):
+    """The read-disjoint scheme over a whole genome (BASELINE config 3): the BED positions of all
+    contigs are cut into world_size runs of equal size (plan_partitions); a run may span contigs
+    and may end inside one.  Every read goes to exactly one rank, by its start: rank g owns the
+    reads from the start of its first range up to the start of rank g+1's first range (rank 0 from
+    the beginning, the last rank to the end).  When rank g+1 starts on the contig rank g ends on
+    (`spill`), g's reads reach into positions g+1 owns - at most `tail` behind g+1's start, which
+    the caller guarantees by tail >= max_read_span - so g's job also covers the BED positions in
+    [next_start, next_start + tail): those tail_rows rows come last in the job's row order and are
+    what travels to rank g+1 (exchange_boundaries), whose first tail_rows rows they are.  A rank
+    whose successor starts a new contig has no spill: nothing its reads cover belongs to anyone
+    else.  Raises when a tail would reach two ranks far or a rank is empty.
+    -> dict(ranges=[(ref,start,end)...], bed={ref: [[s,e]...]} for the job, own_rows, tail_rows,
+    spill, rec_lo / rec_hi = (ref,pos) keys of the reads the rank is given (None = open end))."""
+    parts = plan_partitions(bed, world_size)
+    if any(not p for p in parts):
+        raise ValueError(f"fewer BED positions than ranks: {world_size} ranks")
+    ranges = parts[rank]
+    job_bed = {}
+    for r, s, e in ranges:
+        job_bed.setdefault(r, []).append([s, e])
+    own = sum(e - s for _, s, e in ranges)
+    spill, tail_rows = False, 0
+    rec_lo = None if rank == 0 else (ranges[0][0], ranges[0][1])
+    rec_hi = None
+    if rank + 1 < world_size:
+        nref, nstart, _ = parts[rank + 1][0]
+        rec_hi = (nref, nstart)
+        if nref == ranges[-1][0]:
+            spill = True
+            lim = nstart + tail
+            ext = [[max(s, nstart), min(e, lim)] for r, s, e in parts[rank + 1] if r == nref and s < lim]
+            tail_rows = sum(e - s for s, e in ext)
+            if tail_rows != sum(min(e, lim) - max(s, nstart) for s, e in bed[nref] if s < lim and e > nstart):
+                raise ValueError(f"rank {rank + 1}'s share is shorter than the {tail}-position boundary tail")
+            for s, e in ext:
+                if job_bed[nref][-1][1] == s:
+                    job_bed[nref][-1][1] = e
+                else:
+                    job_bed[nref].append([s, e])
+    return dict(ranges=ranges, bed=job_bed, own_rows=own, tail_rows=tail_rows, spill=spill,
+                rec_lo=rec_lo, rec_hi=rec_hi)
+
+
+def owned_record_span(batch, share):
+    """(lo, hi): the coordinate-sorted records a rank of the read-disjoint scheme is given."""
+    key = batch.ref_id.astype(np.int64) << 32 | batch.pos.astype(np.int64)
+    lo = 0 if share["rec_lo"] is None else int(np.searchsorted(key, (share["rec_lo"][0] << 32) | share["rec_lo"][1], "left"))
+    hi = batch.n if share["rec_hi"] is None else int(np.searchsorted(key, (share["rec_hi"][0] << 32) | share["rec_hi"][1], "left"))
+    return lo, hi
+
+
 def exchange_boundaries(dist, torch, job, own_rows, tail_rows, tail, rank, world_size, device="cuda",
                         stage="cuda"):
     """After job.compute(): all-gather the tail rows and add the left neighbour's onto this

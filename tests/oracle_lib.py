@@ -171,6 +171,31 @@ def pileup(opts, ref_len, bed, batch, shards=None, n_shards=None, parallelism=1)
     return out_ref[:n], out_pos[:n], out_vals[:n]
 
 
+def whole_contig_column_sums(opts, L, batch, threads=16):
+    """The 11 column sums (Depth, A+ .. X-) of the oracle's rows over ALL of one contig, worked as
+    `threads` position ranges on one thread each - independent jobs with a read halo, like the
+    reference's own (pileup.go:862-932); with stitching the BED is padded by two spans as well and
+    the padding's rows are dropped, which gives the one-job rows for any cut.
+    -> (sums[11] as Python ints, seconds)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    span = int(opts.max_read_span)
+    pad_r, pad_b = (2 * span + 2, 2 * span + 2) if opts.stitch else (span + 1, 0)
+    edges = [L * i // threads for i in range(threads + 1)]
+
+    def one(i):
+        s, e = edges[i], edges[i + 1]
+        a = int(np.searchsorted(batch.pos, max(0, s - pad_r), "left"))
+        b = int(np.searchsorted(batch.pos, e + (pad_r if opts.stitch else 0), "left"))
+        bs, be = max(0, s - pad_b), min(L, e + pad_b)
+        _, _, v = pileup(opts, [L], {0: [[bs, be]]}, batch.slice(a, b), parallelism=1)
+        return v[s - bs:s - bs + (e - s)].sum(axis=0, dtype=np.uint64)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        tot = sum(ex.map(one, range(threads)))
+    return [int(x) for x in tot], time.perf_counter() - t0
+
+
 def pileup_per_read(opts, ref_len, bed, batch, shards=None, n_shards=None, parallelism=1, feat_cap=None):
     """The oracle with perReadNeeded set: (ref, pos, vals, off[4P+1], feats[FEAT_DTYPE])."""
     lib = load()

@@ -518,6 +518,9 @@ def test_full_size_chr1_30x_properties(chr1_30x):
         assert sum(sums[1:]) == sums[0]
         job.compute()
         assert job.column_sums() == sums
+        # all 11 column sums of the oracle's rows over the WHOLE contig (16 position ranges)
+        want_sums, _ = O.whole_contig_column_sums(opts, L, rb, 16)
+        assert want_sums == sums
         _oracle_windows(job, opts, L, rb)
         # linearity: halves of the records, in two jobs, merged on the device
         half = rb.n // 2
@@ -534,6 +537,82 @@ def test_full_size_chr1_30x_properties(chr1_30x):
             for r0 in range(0, L, step):
                 n = min(step, L - r0)
                 assert (ja.rows(r0, n)[2] == job.rows(r0, n)[2]).all(), r0
+
+
+def test_full_size_c3_one_ranks_share_rank3_of_8():
+    """BASELINE.json configs[2] (3.1 Gb at 30x over 8 GPUs), ONE rank's share at its full size on
+    the one GPU there is: rank 3 of 8 owns 386 M positions from the middle of chr6 to the first
+    7.6 Mb of chr9 - three contig boundaries inside the share, a cut inside a contig at either
+    end - and is given the ~77 M reads that start there (partition.boundary_share, the code
+    bench.py --config c3 runs).  Depth over own + tail rows = the aligned bases counted on the
+    host; the 1,024 tail rows that would travel to rank 4 come out of bp_rows_export as bp_rows
+    has them, hold what the rank's reads put behind its end, and equal the oracle's; oracle rows
+    on 100 kb windows either side of every contig boundary and at both ends of the share."""
+    import torch
+    from bench import HG38_LENS, kept_aligned_bases
+    from bio_amd import partition as P
+    world, rank, tail = 8, 3, 1024
+    gbed = {r: [[0, l]] for r, l in enumerate(HG38_LENS)}
+    share = P.boundary_share(gbed, world, rank, tail)
+    ranges = share["ranges"]
+    assert [r for r, _, _ in ranges] == [5, 6, 7, 8] and ranges[0][1] > 0 and ranges[-1][2] < HG38_LENS[8]
+    assert share["spill"] and share["tail_rows"] == tail and share["own_rows"] == sum(HG38_LENS) * 4 // 8 - sum(HG38_LENS) * 3 // 8
+    last = ranges[-1]
+    regions = [(r, s, (e if (r, s, e) == last else e - 1000), 30.0) for r, s, e in ranges]
+    sb = synth.generate(regions, seed=synth.SEED + rank, threads=16)
+    rb = sb.to_record_batch()
+    key = rb.ref_id.astype(np.int64) << 32 | rb.pos.astype(np.int64)
+    rb = rb.slice(int(np.searchsorted(key, (ranges[0][0] << 32) | ranges[0][1], "left")), rb.n)
+    key = rb.ref_id.astype(np.int64) << 32 | rb.pos.astype(np.int64)
+    assert 70_000_000 < rb.n < 85_000_000
+    B = kept_aligned_bases(rb, dict(flag_exclude=0xF00, mapq=60))
+    opts = O.make_opts()
+    row0 = {}  # first row of each range
+    acc = 0
+    for r, s, e in ranges:
+        row0[r] = (acc, s)
+        acc += e - s
+    with snp.PileupJob(opts, HG38_LENS) as job:
+        job.set_bed(share["bed"])
+        job.reserve(rb.n, len(rb.cigar) * 4 + len(rb.seq) + len(rb.qual))
+        job.submit(rb)
+        job.finish()
+        own, n_tail = share["own_rows"], share["tail_rows"]
+        assert job.num_rows == own + n_tail
+        sums = job.column_sums()
+        assert sums[0] == B and sum(sums[1:]) == B
+
+        def check(ref, w0, w1):
+            lo = int(np.searchsorted(key, (ref << 32) | max(0, w0 - 600), "left"))
+            hi = int(np.searchsorted(key, (ref << 32) | w1, "left"))
+            wr, wp, wv = O.pileup(opts, HG38_LENS, {ref: [[w0, w1]]}, rb.slice(lo, hi))
+            base, s = row0[ref]
+            gr, gp, gv = job.rows(base + w0 - s, w1 - w0)
+            assert (gr == wr).all() and (gp == wp).all() and (gv == wv).all(), (ref, w0)
+            return gv
+        # both ends of the share (the first rows lack what rank 2's reads would add: so does the oracle here)
+        first = check(ranges[0][0], ranges[0][1], ranges[0][1] + 100_000)
+        assert first[:100, 0].mean() < first[1000:, 0].mean()
+        check(last[0], last[2] - 100_000, last[2])
+        # either side of the three contig boundaries
+        for r, s, e in ranges[:-1]:
+            v = check(r, e - 100_000, e)
+            assert v[-450:].sum() == 0 and v[:90_000, 0].min() > 0  # pairs start 1,000 or more short of the contig's end
+        for r, s, e in ranges[1:]:
+            assert s == 0
+            check(r, 0, 100_000)
+        # the tail: rows [own, own + 1024) = chr9 positions behind the share's end
+        buf = torch.zeros(tail * 11, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        job.rows_export(own, n_tail, buf.data_ptr())
+        exported = buf.cpu().numpy().view(np.uint32).reshape(tail, 11)
+        tr, tp, tv = job.rows(own, n_tail)
+        assert (exported == tv).all() and (tr == last[0]).all() and tp[0] == last[2] and tp[-1] == last[2] + tail - 1
+        lo = int(np.searchsorted(key, (last[0] << 32) | (last[2] - 600), "left"))
+        _, _, wv = O.pileup(opts, HG38_LENS, {last[0]: [[last[2], last[2] + tail]]}, rb.slice(lo, rb.n))
+        assert (tv == wv).all()
+        assert tv[:100, 0].mean() > 5 and tv[700:].sum() == 0  # the reads reach < 1,024 behind the end
+    sb.close()
 
 
 @pytest.mark.parametrize("mode", ["minq20", "minq20_clip5", "stitch_minq20"])

@@ -60,7 +60,15 @@ def test_static_compute_equals_compute_twice_in_a_row(kw):
         for job, ref in zip(jobs, want):
             _doubled(job)
             assert (job.rows()[2] == 2 * ref[2]).all()
+            # the entry point's defining property: the device's free memory is the same before
+            # and after (hipMemGetInfo through torch; the kernels' scratch here is megabytes, so a
+            # hipMalloc slipped into the path would show), while the allocating path, asked for a
+            # buffer it does not have yet, does move it
+            import torch
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info(0)[0]
             job.compute_static()
+            assert torch.cuda.mem_get_info(0)[0] == free0
             got = job.rows()
             assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all() and (got[2] == ref[2]).all()
             assert job.timing().pileup_ms > 0

@@ -9,8 +9,8 @@ for f in $R/bio_amd/variants/lib_*.so; do
   for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"; do
     i=$((i+1))
-    rm -rf /tmp/pmc_$n_$i
-    BENCH_TUNING_NO_CHECK=1 BIO_AMD_LIB=$f timeout -s KILL 200 rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_${n}_$i -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pmc_${n}_$i.log 2>&1 || { echo "pass failed"; tail -3 /tmp/pmc_${n}_$i.log; exit 1; }
+    rm -rf /tmp/pmc_${n}_$i
+    BENCH_TUNING_NO_CHECK=1 BIO_AMD_LIB=$f timeout -s KILL 200 rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_${n}_$i -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > /tmp/pmc_${n}_$i.log 2>&1 || { echo "pass failed"; tail -3 /tmp/pmc_${n}_$i.log; exit 1; }
   done
   python3 - $n <<'PY'
 import csv, glob, sys, collections

@@ -70,6 +70,8 @@ EXPORTS = [
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
     "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch",
+    "bp_inflate_create", "bp_inflate_destroy", "bp_inflate_blocks", "bp_inflate_device_output", "bp_inflate_stream",
+    "bp_inflate_timing", "bp_inflate_last_error",
 ]
 
 HOST_EXPORTS = [
@@ -105,6 +107,11 @@ class bio_pileup_opts(C.Structure):
         ("device", C.c_int32),
         ("devices", C.c_int32),
     ]
+
+
+class bp_bgzf_block(C.Structure):
+    _fields_ = [("in_off", C.c_uint32), ("in_len", C.c_uint32), ("out_off", C.c_uint32), ("out_len", C.c_uint32),
+                ("crc32", C.c_uint32)]
 
 
 class bio_basestrand_tsv_row(C.Structure):
@@ -189,6 +196,21 @@ def load():
     lib.bp_per_read_offsets.restype = C.c_int
     lib.bp_per_read_features.argtypes = [H, C.c_uint64, C.c_uint64, C.c_void_p]
     lib.bp_per_read_features.restype = C.c_int
+    lib.bp_inflate_create.argtypes = [C.c_int32, C.POINTER(H)]
+    lib.bp_inflate_create.restype = C.c_int
+    lib.bp_inflate_destroy.argtypes = [H]
+    lib.bp_inflate_destroy.restype = None
+    lib.bp_inflate_blocks.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int32,
+                                      C.POINTER(C.c_int64)]
+    lib.bp_inflate_blocks.restype = C.c_int
+    lib.bp_inflate_device_output.argtypes = [H]
+    lib.bp_inflate_device_output.restype = C.c_void_p
+    lib.bp_inflate_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.bp_inflate_stream.restype = C.c_int
+    lib.bp_inflate_timing.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.bp_inflate_timing.restype = C.c_int
+    lib.bp_inflate_last_error.argtypes = [H]
+    lib.bp_inflate_last_error.restype = C.c_char_p
     # include/bio_pileup_host.h
     E = [C.c_char_p, C.c_size_t]
     lib.bio_pileup_default_opts.argtypes = [C.POINTER(bio_pileup_opts)]

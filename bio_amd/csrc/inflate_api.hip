@@ -1,0 +1,233 @@
+// inflate_api.hip -- host side of the device BGZF inflate (include/bio_pileup.h, bp_inflate_*).
+//
+// One bp_inflater = one stream with its buffers: the compressed bytes of a batch of BGZF blocks
+// go to the device as they lie in the file, the host says where each block's deflate data
+// starts and ends and where its ISIZE bytes belong in the output (it has parsed the 18-byte block
+// headers and the trailers, bam.cpp), the kernels of inflate_kernels.hip inflate every block and
+// check its CRC-32, and the output comes back to the host and/or stays on the device for
+// bp_submit_bam's record packing.  What bgzf.Reader does under bam.Reader in the reference
+// (encoding/bamprovider/bamprovider.go:417-435).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bio_pileup.h"
+#include "inflate_device.h"
+
+namespace bp {
+void launch_inflate(const uint8_t* comp, const InflateBlock* blks, int n_blocks, uint8_t* out, uint32_t* status,
+                    hipStream_t s);
+void launch_bgzf_crc(const uint8_t* out, const InflateBlock* blks, int n_blocks, const uint32_t* crc_tables,
+                     uint32_t* status, hipStream_t s);
+}
+using namespace bp;
+
+static_assert(sizeof(bp_bgzf_block) == sizeof(InflateBlock), "bp_bgzf_block is shipped as InflateBlock");
+
+namespace {
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+std::string g_inflate_error;
+}  // namespace
+
+struct bp_inflater {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  Buf comp, blks, out, status;  // device
+  uint32_t* tables = nullptr;   // device: CRC tables
+  uint32_t* h_status = nullptr; // pinned
+  size_t h_status_cap = 0;
+  float inflate_ms = 0, crc_ms = 0;
+  std::string err;
+};
+
+namespace {
+
+int ifail(bp_inflater* f, int code, const char* fmt, ...) {
+  char tmp[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tmp, sizeof tmp, fmt, ap);
+  va_end(ap);
+  (f ? f->err : g_inflate_error) = tmp;
+  return code;
+}
+
+#define INF_TRY(f, call)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) return ifail(f, BP_EDEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int grow(bp_inflater* f, Buf& b, size_t need) {
+  if (need <= b.cap) return BP_OK;
+  if (b.p) INF_TRY(f, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t cap = need + need / 4 + 4096;
+  hipError_t e = hipMalloc(&b.p, cap);
+  if (e != hipSuccess) return ifail(f, BP_ENOMEM, "hipMalloc(%zu): %s", cap, hipGetErrorString(e));
+  b.cap = cap;
+  return BP_OK;
+}
+
+const char* status_text(uint32_t s) {
+  switch (s) {
+    case INF_BAD_BLOCK_TYPE: return "invalid deflate block type";
+    case INF_BAD_STORED_LEN: return "stored block length check failed";
+    case INF_BAD_CODE_LENGTHS: return "invalid code lengths";
+    case INF_BAD_CODE: return "invalid literal/length or distance code";
+    case INF_DISTANCE_TOO_FAR: return "match distance reaches in front of the block";
+    case INF_OUTPUT_OVERFLOW: return "more data than ISIZE";
+    case INF_INPUT_OVERRUN: return "deflate stream runs past the block";
+    case INF_OUTPUT_SHORT: return "less data than ISIZE";
+    case INF_BAD_CRC: return "CRC-32 mismatch";
+    default: return "unknown";
+  }
+}
+
+// T and the four "advance by 256 zero bytes" tables of bgzf_crc_kernel
+void crc_tables(uint32_t* t /*[1280]*/) {
+  for (uint32_t n = 0; n < 256; n++) {
+    uint32_t c = n;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+    t[n] = c;
+  }
+  for (int q = 0; q < 4; q++)
+    for (uint32_t b = 0; b < 256; b++) {
+      uint32_t v = b << (8 * q);
+      for (int k = 0; k < 256; k++) v = t[v & 0xffu] ^ (v >> 8);
+      t[256 + 256 * q + b] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bp_inflate_create(int32_t device, bp_inflater** out) {
+  if (!out) return ifail(nullptr, BP_EINVAL, "bp_inflate_create: null argument");
+  *out = nullptr;
+  if (int rc = bp_init(device)) {
+    g_inflate_error = bp_last_error(nullptr);
+    return rc;
+  }
+  bp_inflater* f = new bp_inflater();
+  f->device = device;
+  auto bail = [&](const char* what, hipError_t e) {
+    int rc = ifail(nullptr, BP_EDEVICE, "%s: %s", what, hipGetErrorString(e));
+    bp_inflate_destroy(f);
+    return rc;
+  };
+  hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return bail("hipStreamCreate", e);
+  for (int i = 0; i < 3; i++) {
+    e = hipEventCreate(&f->ev[i]);
+    if (e != hipSuccess) return bail("hipEventCreate", e);
+  }
+  std::vector<uint32_t> t(1280);
+  crc_tables(t.data());
+  e = hipMalloc((void**)&f->tables, 1280 * 4);
+  if (e != hipSuccess) return bail("hipMalloc", e);
+  e = hipMemcpy(f->tables, t.data(), 1280 * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return bail("hipMemcpy", e);
+  *out = f;
+  return BP_OK;
+}
+
+void bp_inflate_destroy(bp_inflater* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  for (Buf* b : {&f->comp, &f->blks, &f->out, &f->status})
+    if (b->p) (void)hipFree(b->p);
+  if (f->tables) (void)hipFree(f->tables);
+  if (f->h_status) (void)hipHostFree(f->h_status);
+  for (hipEvent_t ev : f->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (f->stream) (void)hipStreamDestroy(f->stream);
+  delete f;
+}
+
+int bp_inflate_blocks(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
+                      int64_t n_blocks, uint8_t* out_host, size_t out_bytes, int32_t check_crc, int64_t* bad_block) {
+  if (bad_block) *bad_block = -1;
+  if (!f || n_blocks < 0 || (n_blocks > 0 && (!comp || !blocks)))
+    return ifail(f, BP_EINVAL, "bp_inflate_blocks: bad argument");
+  if (comp_bytes > 0xfffffff0ull || out_bytes > 0xfffffff0ull || n_blocks > 0x7fffffff)
+    return ifail(f, BP_EINVAL, "bp_inflate_blocks: more than 4 GiB in one call");
+  // every block inside the bytes given and inside the output, at most 64 KiB each (SAM spec 4.1)
+  for (int64_t i = 0; i < n_blocks; i++) {
+    const bp_bgzf_block& b = blocks[i];
+    if ((uint64_t)b.in_off + b.in_len > comp_bytes || (uint64_t)b.out_off + b.out_len > out_bytes ||
+        b.out_len > 65536 || b.in_len == 0) {
+      if (bad_block) *bad_block = i;
+      return ifail(f, BP_EINVAL, "bp_inflate_blocks: block %lld does not fit the bytes given (in %u+%u of %zu, out %u+%u of %zu)",
+                   (long long)i, b.in_off, b.in_len, comp_bytes, b.out_off, b.out_len, out_bytes);
+    }
+  }
+  INF_TRY(f, hipSetDevice(f->device));
+  f->inflate_ms = f->crc_ms = 0;
+  if (n_blocks == 0) return BP_OK;
+  // (the bit reader loads whole 256-byte windows up to two ahead: 1 KiB of slack behind the data)
+  if (int rc = grow(f, f->comp, comp_bytes + 1024)) return rc;
+  if (int rc = grow(f, f->blks, (size_t)n_blocks * sizeof(InflateBlock))) return rc;
+  if (int rc = grow(f, f->out, out_bytes + 256)) return rc;
+  if (int rc = grow(f, f->status, (size_t)n_blocks * 4)) return rc;
+  if (f->h_status_cap < (size_t)n_blocks) {
+    if (f->h_status) INF_TRY(f, hipHostFree(f->h_status));
+    f->h_status = nullptr;
+    f->h_status_cap = 0;
+    const size_t cap = (size_t)n_blocks + (size_t)n_blocks / 4 + 256;
+    INF_TRY(f, hipHostMalloc((void**)&f->h_status, cap * 4, hipHostMallocDefault));
+    f->h_status_cap = cap;
+  }
+  INF_TRY(f, hipMemcpyAsync(f->comp.p, comp, comp_bytes, hipMemcpyHostToDevice, f->stream));
+  INF_TRY(f, hipMemcpyAsync(f->blks.p, blocks, (size_t)n_blocks * sizeof(InflateBlock), hipMemcpyHostToDevice, f->stream));
+  INF_TRY(f, hipEventRecord(f->ev[0], f->stream));
+  launch_inflate((const uint8_t*)f->comp.p, (const InflateBlock*)f->blks.p, (int)n_blocks, (uint8_t*)f->out.p,
+                 (uint32_t*)f->status.p, f->stream);
+  INF_TRY(f, hipEventRecord(f->ev[1], f->stream));
+  if (check_crc)
+    launch_bgzf_crc((const uint8_t*)f->out.p, (const InflateBlock*)f->blks.p, (int)n_blocks, f->tables,
+                    (uint32_t*)f->status.p, f->stream);
+  INF_TRY(f, hipEventRecord(f->ev[2], f->stream));
+  INF_TRY(f, hipGetLastError());
+  INF_TRY(f, hipMemcpyAsync(f->h_status, f->status.p, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, f->stream));
+  if (out_host && out_bytes) INF_TRY(f, hipMemcpyAsync(out_host, f->out.p, out_bytes, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipStreamSynchronize(f->stream));
+  (void)hipEventElapsedTime(&f->inflate_ms, f->ev[0], f->ev[1]);
+  (void)hipEventElapsedTime(&f->crc_ms, f->ev[1], f->ev[2]);
+  for (int64_t i = 0; i < n_blocks; i++)
+    if (f->h_status[i] != INF_OK) {
+      if (bad_block) *bad_block = i;
+      return ifail(f, BP_EDATA, "bgzf: corrupt block %lld (%s)", (long long)i, status_text(f->h_status[i]));
+    }
+  return BP_OK;
+}
+
+const uint8_t* bp_inflate_device_output(const bp_inflater* f) { return f ? (const uint8_t*)f->out.p : nullptr; }
+
+int bp_inflate_stream(bp_inflater* f, void** stream) {
+  if (!f || !stream) return ifail(f, BP_EINVAL, "bp_inflate_stream: null argument");
+  *stream = (void*)f->stream;
+  return BP_OK;
+}
+
+int bp_inflate_timing(const bp_inflater* f, float* inflate_ms, float* crc_ms) {
+  if (!f) return BP_EINVAL;
+  if (inflate_ms) *inflate_ms = f->inflate_ms;
+  if (crc_ms) *crc_ms = f->crc_ms;
+  return BP_OK;
+}
+
+const char* bp_inflate_last_error(const bp_inflater* f) { return f ? f->err.c_str() : g_inflate_error.c_str(); }
+
+}  // extern "C"

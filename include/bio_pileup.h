@@ -264,6 +264,43 @@ int64_t bp_algorithmic_bytes(const bp_handle* h);
 const char* bp_last_error(const bp_handle* h); /* h may be NULL: last create/init error */
 void bp_destroy(bp_handle* h);
 
+/* ---- BGZF inflate on the device ---------------------------------------
+ * Replaces what runs in front of processShard in the reference: bam.Reader over bgzf.Reader
+ * behind bamprovider's iterator (encoding/bamprovider/bamprovider.go:417-435; the reader itself is
+ * biogo/hts bgzf, a go.mod dependency absent from the tree: BGZF per SAM spec 4.1, DEFLATE per
+ * RFC 1951).  The caller parses the BGZF block headers (18 bytes: offsets and BSIZE) and
+ * trailers (CRC32, ISIZE) - byte shuffling on a few bytes per 64 KiB - and hands over the
+ * compressed bytes as they lie in the file with one bp_bgzf_block per block; the device
+ * inflates every block (one wavefront per block), checks ISIZE and, when asked, the CRC-32. */
+typedef struct bp_bgzf_block {
+  uint32_t in_off;  /* the block's deflate data (behind its header) in `comp` */
+  uint32_t in_len;  /* BSIZE + 1 - header - 8 */
+  uint32_t out_off; /* where its bytes go in the output: normally the running sum of ISIZE */
+  uint32_t out_len; /* ISIZE (at most 65536); blocks of ISIZE 0 need not be passed */
+  uint32_t crc32;   /* the trailer's CRC32 */
+} bp_bgzf_block;
+typedef struct bp_inflater bp_inflater;
+
+/* One inflater = one HIP stream with its device buffers; calls on one inflater are serial,
+ * inflaters are independent (as handles are). */
+int bp_inflate_create(int32_t device, bp_inflater** out);
+void bp_inflate_destroy(bp_inflater* f);
+/* Inflates n_blocks blocks.  comp/comp_bytes: host memory (pinned memory is copied from
+ * directly); out_host (may be NULL) receives out_bytes of output, which also stays on the device
+ * until the inflater's next call (bp_inflate_device_output).  Returns BP_EDATA for a block that
+ * does not inflate to ISIZE bytes with the trailer's checksum - a corrupt or truncated block,
+ * which the reference's reader refuses too - with its index in *bad_block (may be NULL), BP_EINVAL
+ * for a block table that does not fit the bytes given. */
+int bp_inflate_blocks(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
+                      int64_t n_blocks, uint8_t* out_host, size_t out_bytes, int32_t check_crc, int64_t* bad_block);
+/* The last call's output on the device (out_bytes of it), valid until the next call or destroy;
+ * bp_inflate_stream: the stream it was written on (for callers that order other work behind it). */
+const uint8_t* bp_inflate_device_output(const bp_inflater* f);
+int bp_inflate_stream(bp_inflater* f, void** stream);
+/* HIP-event times of the last call's inflate and CRC kernels */
+int bp_inflate_timing(const bp_inflater* f, float* inflate_ms, float* crc_ms);
+const char* bp_inflate_last_error(const bp_inflater* f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <thread>
 
+#include "../../../include/bio_pileup.h"
 #include "../par.h"
 #include "bio_host.h"
 
@@ -60,16 +61,22 @@ const Deflate& GetDeflate() {
 }
 
 constexpr int kBatchBlocksMax = 256;  // up to 16 MiB inflated per refill (8 and 64 MiB are slower)
-int BatchBlocks() {  // BIO_PILEUP_BATCH_BLOCKS exists for tests of the chunk hand-over and the seeks
+// With the blocks inflated on the device a batch is 4,096 blocks (256 MiB inflated): a block is
+// one wavefront's work for a few milliseconds, and the device holds thousands of wavefronts.
+constexpr int kDeviceBatchBlocks = 4096;
+constexpr int kDeviceParts = 4;  // a batch goes to the device in this many parts, each on a stream of its own
+int BatchBlocks(bool device = false) {  // BIO_PILEUP_BATCH_BLOCKS exists for tests of the chunk hand-over and the seeks
   const char* e = getenv("BIO_PILEUP_BATCH_BLOCKS");
   long v = e && *e ? atol(e) : 0;
-  return v >= 1 && v <= kBatchBlocksMax ? (int)v : kBatchBlocksMax;
+  const int mx = device ? kDeviceBatchBlocks : kBatchBlocksMax;
+  return v >= 1 && v <= mx ? (int)v : mx;
 }
 // A batch's inflated bytes start kHead bytes into its buffer: the unconsumed tail of the previous
 // batch (normally part of one record) is copied in front of them, instead of appending 16 MiB to
 // the old buffer.
 constexpr size_t kHead = 1 << 20;
 constexpr size_t kStdCap = kHead + (size_t)kBatchBlocksMax * 65536 + 64;
+constexpr size_t kDeviceStdCap = kHead + (size_t)kDeviceBatchBlocks * 65536 + 64;
 
 // Inflated bytes live in buffers of one size that go back to a pool when the last chunk that
 // points into them is dropped: fresh 17 MiB allocations would be page-faulted in over and over
@@ -87,11 +94,13 @@ class BufPool {
     static BufPool* g = new BufPool();  // never destroyed: chunks may outlive every reader
     return *g;
   }
-  std::shared_ptr<Buf> Take(size_t need, bool pinned) {
+  // `big`: the device-inflate batch size (its buffers are pooled apart from the 17 MiB ones)
+  std::shared_ptr<Buf> Take(size_t need, bool pinned, bool big = false) {
     Buf* b = nullptr;
-    if (need <= kStdCap) {
+    const size_t std_cap = big ? kDeviceStdCap : kStdCap;
+    if (need <= std_cap) {
       std::lock_guard<std::mutex> lk(mu_);
-      std::vector<Buf*>& f = free_[pinned ? 1 : 0];
+      std::vector<Buf*>& f = free_[(pinned ? 1 : 0) + (big ? 2 : 0)];
       if (!f.empty()) {
         b = f.back();
         f.pop_back();
@@ -99,9 +108,9 @@ class BufPool {
     }
     if (!b) {
       b = new Buf();
-      b->cap = std::max(need, kStdCap);
+      b->cap = std::max(need, std_cap);
       // only standard buffers are worth pinning (the others hold one over-long record)
-      if (pinned && need <= kStdCap) {
+      if (pinned && need <= std_cap) {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, b->cap, hipHostMallocPortable) == hipSuccess) {
           b->p = (uint8_t*)hp;
@@ -121,10 +130,11 @@ class BufPool {
 
  private:
   void Give(Buf* b) {
-    if (b->cap == kStdCap) {
+    if (b->cap == kStdCap || b->cap == kDeviceStdCap) {
+      const bool big = b->cap == kDeviceStdCap;
       std::lock_guard<std::mutex> lk(mu_);
-      std::vector<Buf*>& f = free_[b->pinned ? 1 : 0];
-      if (f.size() < 24) {
+      std::vector<Buf*>& f = free_[(b->pinned ? 1 : 0) + (big ? 2 : 0)];
+      if (f.size() < (big ? 6u : 24u)) {
         f.push_back(b);
         return;
       }
@@ -134,7 +144,7 @@ class BufPool {
     delete b;
   }
   std::mutex mu_;
-  std::vector<Buf*> free_[2];
+  std::vector<Buf*> free_[4];
 };
 }  // namespace
 
@@ -209,6 +219,10 @@ struct BamReader::Impl {
   FILE* f = nullptr;
   bool file_eof = false;     // the batch reader met the end of the file
   bool pinned = false;       // inflate into pinned host memory
+  std::atomic<int> inflate_device{-1};  // >= 0: BGZF blocks are inflated on that HIP device (may be switched on while reading)
+  std::vector<bp_inflater*> inflaters;
+  std::vector<bp_bgzf_block> blk_tab;
+  double dev_inflate_ms = 0;
   std::shared_ptr<Buf> cur;  // inflated bytes not yet consumed: cur->p[rd, end)
   size_t rd = 0, end = 0;
   uint64_t file_pos = 0;  // file offset of the next byte fread returns
@@ -248,6 +262,7 @@ struct BamReader::Impl {
   ~Impl() {
     if (next.valid()) next.wait();
     if (next_raw.valid()) next_raw.wait();
+    for (bp_inflater* x : inflaters) bp_inflate_destroy(x);
     if (f) fclose(f);
   }
 
@@ -268,7 +283,7 @@ struct BamReader::Impl {
     B.eof = false;
     B.err.clear();
     const int fd = fileno(f);
-    const int batch_blocks = BatchBlocks();
+    const int batch_blocks = BatchBlocks(inflate_device >= 0);
     size_t have = 0;
     bool file_end = false;
     auto read_more = [&](size_t want) {  // appends up to `want` file bytes
@@ -331,10 +346,55 @@ struct BamReader::Impl {
     B.end_pos = R.end_pos;
     B.marks.swap(R.marks);
     if (!B.err.empty()) return out;
-    B.buf = BufPool::Get().Take(kHead + R.out_total, pinned);
+    const int idev = inflate_device.load();
+    B.buf = BufPool::Get().Take(kHead + R.out_total, pinned, kHead + R.out_total > kStdCap);
     if (!B.buf) { B.err = "bam: out of memory"; return out; }
     B.size = kHead + R.out_total;
-    if (!R.blks.empty()) {
+    if (idev >= 0 && !R.blks.empty()) {
+      // On the device: the compressed bytes as they lie in the file plus one table entry per block;
+      // CRC-32 and ISIZE are checked there.  The batch is cut into parts that travel and inflate
+      // side by side on streams of their own (copies either way overlap the kernels).
+      blk_tab.clear();
+      for (const RawBatch::Blk& b : R.blks)
+        if (b.isize)
+          blk_tab.push_back({(uint32_t)b.off, (uint32_t)b.clen, (uint32_t)(b.out - kHead), (uint32_t)b.isize,
+                             U32(R.raw.data() + b.off + b.clen)});
+      const size_t nb = blk_tab.size();
+      const size_t parts = std::min<size_t>(kDeviceParts, std::max<size_t>(1, nb / 256));
+      while (inflaters.size() < parts) {
+        bp_inflater* x = nullptr;
+        if (bp_inflate_create(idev, &x) != BP_OK) { B.err = bp_inflate_last_error(nullptr); return out; }
+        inflaters.push_back(x);
+      }
+      std::vector<std::string> errs(parts);
+      std::vector<float> ms(parts, 0.f);
+      auto one = [&](size_t k) {
+        const size_t a = nb * k / parts, e = nb * (k + 1) / parts;
+        if (a == e) return;
+        const uint32_t in_lo = blk_tab[a].in_off, in_hi = blk_tab[e - 1].in_off + blk_tab[e - 1].in_len;
+        const uint32_t out_lo = blk_tab[a].out_off, out_hi = blk_tab[e - 1].out_off + blk_tab[e - 1].out_len;
+        for (size_t i = a; i < e; i++) { blk_tab[i].in_off -= in_lo; blk_tab[i].out_off -= out_lo; }
+        int64_t bad = -1;
+        if (bp_inflate_blocks(inflaters[k], R.raw.data() + in_lo, in_hi - in_lo, blk_tab.data() + a, (int64_t)(e - a),
+                              B.buf->p + kHead + out_lo, out_hi - out_lo, 1, &bad) != BP_OK) {
+          const std::string m = bp_inflate_last_error(inflaters[k]);
+          errs[k] = m.compare(0, 5, "bgzf:") == 0 ? "bgzf: corrupt block (inflate or CRC failure)" : m;
+        }
+        float a_ms = 0, c_ms = 0;
+        bp_inflate_timing(inflaters[k], &a_ms, &c_ms);
+        ms[k] = a_ms + c_ms;
+      };
+      std::vector<std::thread> th;
+      for (size_t k = 1; k < parts; k++) th.emplace_back(one, k);
+      one(0);
+      for (std::thread& t : th) t.join();
+      float mx = 0;
+      for (size_t k = 0; k < parts; k++) {
+        if (!errs[k].empty() && B.err.empty()) B.err = errs[k];
+        mx = std::max(mx, ms[k]);
+      }
+      dev_inflate_ms += mx;
+    } else if (!R.blks.empty()) {
       uint8_t* const dst = B.buf->p;
       const uint8_t* const raw = R.raw.data();
       const std::vector<RawBatch::Blk>& blks = R.blks;
@@ -450,6 +510,8 @@ BamReader::BamReader() : impl_(new Impl) {}
 BamReader::~BamReader() {}
 
 void BamReader::SetPinned(bool on) { impl_->pinned = on; }
+void BamReader::SetDeviceInflate(int device) { impl_->inflate_device.store(device); }
+double BamReader::DeviceInflateSeconds() const { return impl_->dev_inflate_ms * 1e-3; }
 
 std::string BamReader::Open(const std::string& path) {
   impl_->f = fopen(path.c_str(), "rb");

@@ -110,6 +110,13 @@ class BamReader {
   // Inflate into pinned host memory (hipHostMalloc), which bp_submit_bam copies from without
   // staging.  Before Open().
   void SetPinned(bool on);
+  // Inflate BGZF blocks on HIP device `device` (bp_inflate_blocks: one wavefront per block, CRC-32
+  // checked there) instead of on the host threads; the inflated bytes come back into the same
+  // (pinned) buffers.  Batches are larger then (4,096 blocks instead of 256: the device wants
+  // thousands of blocks in flight).  -1: host.  Any time: batches already read ahead stay as they are.
+  void SetDeviceInflate(int device);
+  // Seconds the device spent in the inflate + CRC kernels, and bytes they produced.
+  double DeviceInflateSeconds() const;
   // True when the next Next() has to bring in more of the file first: the buffers move then,
   // and the pointers of Raw records handed out so far stop being valid.
   bool NextRefills() const;

@@ -580,6 +580,10 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     (void)bp_init(opts.Device);
     return bp_last_error(nullptr);
   }
+  // From here on BGZF blocks are inflated on the device (what the reader has read ahead so far,
+  // the header's blocks among it, went through the host threads; BIO_PILEUP_HOST_INFLATE=1 keeps it
+  // that way, as before round 3).
+  if (const char* e = getenv("BIO_PILEUP_HOST_INFLATE"); !(e && *e && *e != '0')) bam.SetDeviceInflate(opts.Device);
   // -devices N | all: N logical devices, mapped round-robin onto the physical ones
   std::vector<int> devices;
   if (opts.Devices != 0) {
@@ -899,10 +903,10 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
             "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
-            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) total_s=%.3f\n",
+            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f total_s=%.3f\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
             index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, st.close_wait_s,
-            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), st.total_s);
+            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), st.total_s);
   return "";
 }
 

@@ -47,7 +47,15 @@ struct WaveLds {
   uint16_t lit_cnt[16];               // codes per length
   uint16_t dist_cnt[16];
   uint8_t lens[320];                  // code lengths of the block being set up
+  uint32_t dump[2];                   // where lanes that have nothing to store store (see below)
 };
+
+// Lane-dependent BRANCHES are kept out of the serial phases: where the compiler merges the join of
+// such a branch with a block that also carries the decoder's (wave-uniform) state, its uniformity
+// analysis has to call that state divergent, and from there on the bit buffer lives in vector
+// registers and every loop runs under an exec mask.  So lanes with nothing to store store to a
+// dump slot (an address select, no branch), and the state is passed through v_readfirstlane
+// behind the few lane-parallel regions that do branch (table build, batch write).
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void lds_fence() { __builtin_amdgcn_wave_barrier(); }
@@ -77,8 +85,8 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len) {
 // distance, 2 the code-length code.  Returns false for an over-subscribed set of lengths
 // (incomplete sets are let through: a code nobody assigned decodes to an error when it comes).
 template <int MODE>
-__device__ bool build_table(const uint8_t* lens, int n_sym, uint32_t* tab, uint16_t* sorted, uint16_t* cnt_out,
-                            int lane) {
+__device__ __forceinline__ bool build_table(const uint8_t* lens, int n_sym, uint32_t* tab, uint16_t* sorted, uint16_t* cnt_out,
+                                            uint32_t* dump, int lane) {
   constexpr int R = MODE == 0 ? 5 : 1;  // rounds of 64 symbols
   constexpr int ROOT = MODE == 0 ? kLitRoot : MODE == 1 ? kDistRoot : kClRoot;
   uint32_t len[R];
@@ -107,8 +115,9 @@ __device__ bool build_table(const uint8_t* lens, int n_sym, uint32_t* tab, uint1
       idx += c;
     }
   }
-  for (int k = lane; k < (1 << ROOT); k += 64) tab[k] = 0;
-  if (lane < 16) cnt_out[lane] = (uint16_t)mycnt;
+  for (int k0 = 0; k0 < (1 << ROOT); k0 += 64) tab[k0 + lane] = 0;  // (every loop's trip count is wave-uniform,
+  // so that the compiler keeps the decoder's state in scalar registers: a lane-dependent exit makes all of it 'divergent')
+  *(lane < 16 ? &cnt_out[lane] : (uint16_t*)dump) = (uint16_t)mycnt;
   lds_fence();
   for (int L = 1; L <= 15; L++) {
     const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, L);
@@ -120,18 +129,18 @@ __device__ bool build_table(const uint8_t* lens, int n_sym, uint32_t* tab, uint1
     for (int r = 0; r < R; r++) {
       const bool mine = len[r] == (uint32_t)L;
       const unsigned long long m = __ballot(mine);
-      if (mine) {
+      if (m) {
         const uint32_t rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         const uint32_t sym = (uint32_t)(r * 64 + lane);
-        sorted[offs + rank] = (uint16_t)sym;
+        *(mine ? &sorted[offs + rank] : (uint16_t*)dump) = (uint16_t)sym;
         if (L <= ROOT) {
           const uint32_t rev = __brev(first + rank) >> (32 - L);
           const uint32_t e = MODE == 0 ? lit_entry(sym, (uint32_t)L) : MODE == 1 ? dist_entry(sym, (uint32_t)L)
                                                                                  : ((uint32_t)L | (sym << 16));
-          for (uint32_t k = rev; k < (1u << ROOT); k += (1u << L)) tab[k] = e;
+          for (uint32_t j = 0; j < (1u << (ROOT - L)); j++) *(mine ? &tab[rev + (j << L)] : dump) = e;
         }
+        base += (uint32_t)__popcll(m);
       }
-      base += (uint32_t)__popcll(m);
     }
   }
   lds_fence();
@@ -182,6 +191,16 @@ struct Bits {
       }
     }
   }
+  // back to scalar registers behind a lane-parallel region
+  __device__ __forceinline__ void uniform() {
+    buf = ((uint64_t)rfl((uint32_t)(buf >> 32)) << 32) | rfl((uint32_t)buf);
+    cnt = (int)rfl((uint32_t)cnt);
+    idx = (int)rfl((uint32_t)idx);
+    const uintptr_t f = (uintptr_t)fetch;
+    fetch = (const uint32_t*)(((uintptr_t)rfl((uint32_t)(f >> 32)) << 32) | rfl((uint32_t)f));
+    loaded_bits = (int64_t)(((uint64_t)rfl((uint32_t)((uint64_t)loaded_bits >> 32)) << 32) | rfl((uint32_t)loaded_bits));
+    base_bits = (int64_t)(((uint64_t)rfl((uint32_t)((uint64_t)base_bits >> 32)) << 32) | rfl((uint32_t)base_bits));
+  }
   __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); }
   __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
   __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
@@ -213,36 +232,42 @@ __device__ __forceinline__ int slow_decode(uint64_t buf, const uint16_t* cnt, co
 __device__ __forceinline__ void write_batch(const WaveLds& S, uint8_t* o, int total, int lane) {
   for (int p0 = 0; p0 < total; p0 += 64) {
     const int p = p0 + lane;
-    if (p < total) {
-      int s = p;
-      uint32_t val;
-      for (;;) {
+    int s = p;
+    uint32_t val = 0;
+    bool busy = p < total;
+    while (__ballot(busy)) {  // (a wave-uniform exit)
+      if (busy) {
         // the token that covers s: the last one starting at or before it
         int t = 0;
 #pragma unroll
-        for (int step = 32; step; step >>= 1) {
-          const int c = t + step;
-          if (S.off[c & 63] <= s) t = c;  // (off of unused slots is INT_MAX; c <= 63 always: t + step < 64)
-        }
+        for (int step = 32; step; step >>= 1)
+          if (S.off[t + step] <= s) t += step;  // (off of unused slots is INT_MAX; t + step <= 63)
         const uint32_t tk = S.tok[t];
-        if (tk >> 31) { val = tk & 0xffu; break; }
-        const int to = S.off[t];
-        const int L = (int)((tk >> 16) & 0x1ffu), D = (int)(tk & 0xffffu), i = s - to;
-        int j = i;
-        if (D < L) {
-          if (D == 1) j = 0;
-          else {
-            int q = (int)((float)i * __builtin_amdgcn_rcpf((float)D));
-            j = i - q * D;
-            if (j < 0) j += D;
-            else if (j >= D) j -= D;
+        if (tk >> 31) {
+          val = tk & 0xffu;
+          busy = false;
+        } else {
+          const int to = S.off[t];
+          const int L = (int)((tk >> 16) & 0x1ffu), D = (int)(tk & 0xffffu), i = s - to;
+          int j = i;
+          if (D < L) {
+            if (D == 1) j = 0;
+            else {
+              const int q = (int)((float)i * __builtin_amdgcn_rcpf((float)D));
+              j = i - q * D;
+              if (j < 0) j += D;
+              else if (j >= D) j -= D;
+            }
+          }
+          s = to - D + j;
+          if (s < 0) {
+            val = o[s];
+            busy = false;
           }
         }
-        s = to - D + j;
-        if (s < 0) { val = o[s]; break; }
       }
-      o[p] = (uint8_t)val;
     }
+    if (p < total) o[p] = (uint8_t)val;
   }
 }
 
@@ -270,24 +295,30 @@ __device__ uint32_t inflate_one(const uint8_t* __restrict__ comp, const InflateB
       const int64_t at = B.consumed() >> 3;
       if (at + len > (int64_t)blk.in_len) return INF_INPUT_OVERRUN;
       if (out_pos + (int)len > out_len) return INF_OUTPUT_OVERFLOW;
-      for (uint32_t i = lane; i < len; i += 64) obase[out_pos + i] = data[at + i];
+      // (lanes behind the end copy the last byte once more)
+      for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+        const uint32_t i = min(i0 + (uint32_t)lane, len - 1);
+        obase[out_pos + i] = data[at + i];
+      }
       out_pos += (int)len;
       B.seat(data, (uint32_t)(at + len), lane);
     } else {
+      int hlit = 288, hdist = 32;
       if (btype == 1) {
-        // fixed code (RFC 1951 3.2.6)
-        for (int s = lane; s < 288; s += 64) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+        // fixed code (RFC 1951 3.2.6): 288 literal/length codes of 8, 9, 7, 8 bits, 32 distance codes of 5
+        for (int s0 = 0; s0 < 320; s0 += 64) {
+          const int s = s0 + lane;
+          S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
+        }
         lds_fence();
-        build_table<0>(S.lens, 288, S.lit_tab, S.lit_sorted, S.lit_cnt, lane);
-        if (lane < 32) S.lens[lane] = 5;
-        lds_fence();
-        build_table<1>(S.lens, 32, S.dist_tab, S.dist_sorted, S.dist_cnt, lane);
       } else {
         B.refill();
-        const int hlit = (int)B.take(5) + 257, hdist = (int)B.take(5) + 1, hclen = (int)B.take(4) + 4;
+        hlit = (int)B.take(5) + 257;
+        hdist = (int)B.take(5) + 1;
+        const int hclen = (int)B.take(4) + 4;
         if (hlit > 286 || hdist > 30) return INF_BAD_CODE_LENGTHS;
         // the code-length code: 3 bits each, in the order of RFC 1951 3.2.7
-        if (lane < 19) S.lens[lane] = 0;
+        *(lane < 19 ? &S.lens[lane] : (uint8_t*)&S.dump[0]) = 0;
         lds_fence();
         for (int k = 0; k < hclen; k++) {
           B.refill();
@@ -297,12 +328,12 @@ __device__ uint32_t inflate_one(const uint8_t* __restrict__ comp, const InflateB
           S.lens[ord] = (uint8_t)v;
         }
         lds_fence();
-        if (!build_table<2>(S.lens, 19, S.dist_tab, S.lit_sorted, S.lit_cnt, lane)) return INF_BAD_CODE_LENGTHS;
+        if (!build_table<2>(S.lens, 19, S.dist_tab, S.lit_sorted, S.lit_cnt, S.dump, lane)) return INF_BAD_CODE_LENGTHS;
         // the literal/length and distance code lengths, run-length coded
+        // (S.lens is reused for the result: the code-length code's own lengths are in its table now)
         const int n_len = hlit + hdist;
         int i = 0;
         uint32_t prev = 0;
-        // (S.lens is reused for the result: the code-length code's own lengths are in its table now)
         while (i < n_len) {
           B.refill();
           const uint32_t e = rfl(S.dist_tab[B.peek(kClRoot)]);
@@ -328,18 +359,27 @@ __device__ uint32_t inflate_one(const uint8_t* __restrict__ comp, const InflateB
               prev = 0;
             }
             if (i + (int)rep > n_len) return INF_BAD_CODE_LENGTHS;
-            for (uint32_t k = lane; k < rep; k += 64) S.lens[i + k] = (uint8_t)v;
+            // (at most 138: three stores, each lane its own byte)
+#pragma unroll
+            for (uint32_t k0 = 0; k0 < 192; k0 += 64) {
+              uint8_t* dst = k0 + lane < rep ? &S.lens[i + k0 + lane] : (uint8_t*)&S.dump[0];
+              *dst = (uint8_t)v;
+            }
             i += (int)rep;
           }
         }
         lds_fence();
         if (rfl(S.lens[256]) == 0) return INF_BAD_CODE_LENGTHS;  // no end-of-block code
-        // distance lengths to a place of their own before the literal table build reads S.lens
-        uint32_t dl = lane < hdist ? S.lens[hlit + lane] : 0;
-        if (!build_table<0>(S.lens, hlit, S.lit_tab, S.lit_sorted, S.lit_cnt, lane)) return INF_BAD_CODE_LENGTHS;
-        if (lane < 32) S.lens[lane] = (uint8_t)dl;
+      }
+      {
+        // the distance lengths are taken out before the literal table's build reuses S.lens
+        const uint32_t dl = lane < hdist ? S.lens[hlit + lane] : 0;
+        if (!build_table<0>(S.lens, hlit, S.lit_tab, S.lit_sorted, S.lit_cnt, S.dump, lane)) return INF_BAD_CODE_LENGTHS;
+        *(lane < 32 ? &S.lens[lane] : (uint8_t*)&S.dump[0]) = (uint8_t)dl;
         lds_fence();
-        if (!build_table<1>(S.lens, 32, S.dist_tab, S.dist_sorted, S.dist_cnt, lane)) return INF_BAD_CODE_LENGTHS;
+        if (!build_table<1>(S.lens, 32, S.dist_tab, S.dist_sorted, S.dist_cnt, S.dump, lane)) return INF_BAD_CODE_LENGTHS;
+        B.uniform();
+        out_pos = (int)rfl((uint32_t)out_pos);
       }
       // the block's symbols, 64 tokens at a time
       for (;;) {
@@ -406,8 +446,9 @@ __device__ uint32_t inflate_one(const uint8_t* __restrict__ comp, const InflateB
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         write_batch(S, obase + out_pos, total, lane);
         lds_fence();
-        out_pos += total;
-        if (eob) break;
+        B.uniform();
+        out_pos = (int)rfl((uint32_t)(out_pos + total));
+        if (rfl((uint32_t)eob)) break;
       }
     }
     if (B.consumed() > in_bits) return INF_INPUT_OVERRUN;

@@ -70,11 +70,75 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// Device buffers and pinned staging memory of finished jobs are kept for the next job of the
+// process instead of going back to the driver: a whole-genome run opens a job per 2^26 positions,
+// and hipMalloc / hipFree of its gigabytes (rows, payload, cores) and hipHostMalloc of its pinned
+// staging were a third of a job's time on the submitter and closer threads.  At most kCacheBytes
+// per process stay cached; an allocation that fails empties the cache and tries once more.
+// BP_NO_CACHE=1 turns it off.
+constexpr size_t kCacheBytes = (size_t)48 << 30, kCacheMinBytes = (size_t)1 << 20;
+struct DevCache {
+  struct E { void* p; size_t cap; int dev; };
+  std::mutex mu;
+  std::vector<E> v;
+  size_t bytes = 0;
+  bool off = false;
+  DevCache() {
+    const char* e = getenv("BP_NO_CACHE");
+    off = e && *e && *e != '0';
+  }
+  // the smallest cached buffer of `dev` that holds `need` without being more than twice as large
+  void* take(int dev, size_t need, size_t* cap) {
+    std::lock_guard<std::mutex> lk(mu);
+    size_t best = SIZE_MAX;
+    for (size_t k = 0; k < v.size(); k++)
+      if (v[k].dev == dev && v[k].cap >= need && v[k].cap / 2 <= need + kCacheMinBytes && (best == SIZE_MAX || v[k].cap < v[best].cap))
+        best = k;
+    if (best == SIZE_MAX) return nullptr;
+    void* p = v[best].p;
+    *cap = v[best].cap;
+    bytes -= v[best].cap;
+    v.erase(v.begin() + (ptrdiff_t)best);
+    return p;
+  }
+  void give(int dev, void* p, size_t cap) {  // with `dev` current
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!off && cap >= kCacheMinBytes && bytes + cap <= kCacheBytes && v.size() < 256) {
+        v.push_back({p, cap, dev});
+        bytes += cap;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void flush(int dev) {  // with `dev` current
+    std::vector<E> out;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t k = 0; k < v.size();)
+        if (v[k].dev == dev) {
+          out.push_back(v[k]);
+          bytes -= v[k].cap;
+          v.erase(v.begin() + (ptrdiff_t)k);
+        } else {
+          k++;
+        }
+    }
+    for (const E& e : out) (void)hipFree(e.p);
+  }
+};
+DevCache& dev_cache() {
+  static DevCache* c = new DevCache();  // never destroyed: the HIP runtime may be gone by then
+  return *c;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
-  void release() {
-    if (p) (void)hipFree(p);
+  void release(int dev) {  // with `dev` current
+    dev_cache().give(dev, p, cap);
     p = nullptr;
     cap = 0;
   }
@@ -87,6 +151,7 @@ struct Staging {  // pinned host memory of one slice in flight; each part alloca
   uint8_t* raw = nullptr;     // ... record bytes gathered here when they cannot go straight from the caller's memory
   size_t raw_cap = 0;
   hipEvent_t done = nullptr;
+  int dev = -1;  // the device `done` belongs to
   bool busy = false;
 };
 
@@ -349,13 +414,23 @@ int ensure(bp_handle* h, DevBuf& b, size_t need, size_t keep) {
   if (need <= b.cap) return 0;
   size_t cap = std::max(need, b.cap + b.cap / 2);
   cap = (cap + 255) & ~(size_t)255;
-  void* np = nullptr;
-  HIP_TRY(h, hipMalloc(&np, cap));
+  void* np = dev_cache().take(h->device, cap, &cap);
+  if (!np) {
+    hipError_t e = hipMalloc(&np, cap);
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      dev_cache().flush(h->device);
+      e = hipMalloc(&np, cap);
+    }
+    HIP_TRY(h, e);
+  }
   if (b.p && keep) {
     HIP_TRY(h, hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
-  if (b.p) (void)hipFree(b.p);
+  // (work queued on the stream may still read the old buffer: it is only handed on after a sync)
+  if (b.p && !keep) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  dev_cache().give(h->device, b.p, b.cap);
   b.p = np;
   b.cap = cap;
   return 0;
@@ -814,10 +889,42 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
   return 0;
 }
 
+// Pinned staging of finished jobs, for the next job (see DevCache; pinned memory is not tied to a device).
+struct StagePool {
+  std::mutex mu;
+  std::vector<Staging> v;
+};
+StagePool& stage_pool() {
+  static StagePool* p = new StagePool();
+  return *p;
+}
+void free_stage(Staging& s) {
+  if (s.cores) (void)hipHostFree(s.cores);
+  if (s.blob) (void)hipHostFree(s.blob);
+  if (s.items) (void)hipHostFree(s.items);
+  if (s.raw) (void)hipHostFree(s.raw);
+  if (s.done) (void)hipEventDestroy(s.done);
+  s = Staging();
+}
+
 int acquire_stage(bp_handle* h, Staging** out, bool stream_mode, size_t raw_bytes) {
   Staging& s = h->stage[h->cur_stage];
   h->cur_stage ^= 1;
-  if (!s.done) HIP_TRY(h, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (!s.done) {
+    // a finished job's staging that already has what this kind of submit needs, if there is one
+    StagePool& sp = stage_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    for (size_t k = 0; k < sp.v.size(); k++)
+      if (sp.v[k].dev == h->device && (stream_mode ? sp.v[k].items != nullptr : sp.v[k].cores != nullptr)) {
+        s = sp.v[k];
+        sp.v.erase(sp.v.begin() + (ptrdiff_t)k);
+        break;
+      }
+  }
+  if (!s.done) {
+    HIP_TRY(h, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    s.dev = h->device;
+  }
   if (s.busy) {
     HIP_TRY(h, hipEventSynchronize(s.done));
     s.busy = false;
@@ -1898,13 +2005,19 @@ void bp_destroy(bp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf* b : {&h->d_raw, &h->d_pack, &h->d_coarse, &h->d_items, &h->d_iv_ref, &h->d_pr_off, &h->d_pr_tiles, &h->d_pr_tile0, &h->d_pr_tile_lo, &h->d_pr_feat, &h->d_seq8, &h->d_refname, &h->d_txt_len, &h->d_txt_tile, &h->d_txt_out, &h->d_cores, &h->d_blob, &h->d_mate, &h->d_windows, &h->d_r0, &h->d_r1, &h->d_iv_start,
                     &h->d_iv_end, &h->d_iv_row, &h->d_rows, &h->d_err, &h->d_sums, &h->d_qthr, &h->d_dbg, &h->d_ref_first})
-    b->release();
+    b->release(h->device);
   for (Staging& s : h->stage) {
-    if (s.cores) (void)hipHostFree(s.cores);
-    if (s.blob) (void)hipHostFree(s.blob);
-    if (s.items) (void)hipHostFree(s.items);
-    if (s.raw) (void)hipHostFree(s.raw);
-    if (s.done) (void)hipEventDestroy(s.done);
+    if (!s.done) continue;
+    s.busy = false;  // (the stream has been synchronised)
+    StagePool& sp = stage_pool();
+    std::unique_lock<std::mutex> lk(sp.mu);
+    if (!dev_cache().off && sp.v.size() < 6) {
+      sp.v.push_back(s);
+      s = Staging();
+    } else {
+      lk.unlock();
+      free_stage(s);
+    }
   }
   for (hipEvent_t e : h->ev)
     if (e) (void)hipEventDestroy(e);

@@ -44,17 +44,38 @@ n = rb.n
 sb.close()
 del rb
 exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
-env = dict(os.environ, BIO_PILEUP_STATS="1", BP_PROFILE="1")
-t0 = time.time()
-r = subprocess.run([exe, "-bed", bed, "-format", fmt, *extra, "-out", os.path.join(d, "o"), bam, fa],
-                   capture_output=True, text=True, env=env)
-wall = time.time() - t0
-print(r.stderr.strip()[-2600:], flush=True)
-outs = [p for p in os.listdir(d) if p.startswith("o.")]
-size = sum(os.path.getsize(os.path.join(d, p)) for p in outs)
-print(f"bio-pileup -bed all -format {fmt} {' '.join(extra)}: rc {r.returncode}, {wall:.1f} s wall, "
-      f"{n / wall / 1e6:.2f} M records/s, output {size / 1e9:.2f} GB in {outs}", flush=True)
-for p in [bam, fa, bed] + [os.path.join(d, p) for p in outs]:
+import hashlib
+rc_all, sums = 0, {}
+# E2E_MODES: "device" (BGZF inflate on the GPU, the default of the driver) and/or "host"
+for mode in os.environ.get("E2E_MODES", "device,host").split(","):
+    env = dict(os.environ, BIO_PILEUP_STATS="1", BP_PROFILE="1")
+    if mode == "host":
+        env["BIO_PILEUP_HOST_INFLATE"] = "1"
+    t0 = time.time()
+    r = subprocess.run([exe, "-bed", bed, "-format", fmt, *extra, "-out", os.path.join(d, "o"), bam, fa],
+                       capture_output=True, text=True, env=env)
+    wall = time.time() - t0
+    print(r.stderr.strip()[-2600:], flush=True)
+    outs = sorted(p for p in os.listdir(d) if p.startswith("o."))
+    size = sum(os.path.getsize(os.path.join(d, p)) for p in outs)
+    h = hashlib.md5()
+    for p in outs:
+        with open(os.path.join(d, p), "rb") as f:
+            while True:
+                blk = f.read(1 << 24)
+                if not blk:
+                    break
+                h.update(blk)
+    sums[mode] = h.hexdigest()
+    print(f"[{mode} inflate] bio-pileup -bed all -format {fmt} {' '.join(extra)}: rc {r.returncode}, {wall:.2f} s wall, "
+          f"{n / wall / 1e6:.2f} M records/s, output {size / 1e9:.2f} GB in {outs}, md5 {sums[mode]}", flush=True)
+    rc_all |= r.returncode
+    for p in outs:
+        os.remove(os.path.join(d, p))
+if len(set(sums.values())) > 1:
+    print("OUTPUTS DIFFER between inflate modes", sums, flush=True)
+    rc_all |= 1
+for p in [bam, fa, bed]:
     os.remove(p)
 os.rmdir(d)
-sys.exit(r.returncode)
+sys.exit(rc_all)

@@ -195,14 +195,14 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
             fld = ln.split(b"\t")
             if int(fld[1]) != i + 1 or [int(x) for x in fld[3:11]] != dv[i][1:9].tolist() or fld[2] != bytes(seq[i:i + 1]):
                 raise SystemExit(f"e2e: line {i + 2} of the output differs from the device rows")
-        m = re.search(r"read_s=([0-9.]+).*waiting for inflated blocks ([0-9.]+).*total_s=([0-9.]+)", r.stderr)
+        m = re.search(r"read_s=([0-9.]+).*waiting for inflated blocks ([0-9.]+).*device_inflate_s=([0-9.]+) total_s=([0-9.]+)", r.stderr)
         blk = {"value": round(B / wall / 1e9, 3), "unit": "Gbase/s", "wall_s": round(wall, 2),
                "what": f"bio-pileup {' '.join(x for x in flags if not x.startswith('/'))}: BAM ({os.path.getsize(bam) / 1e9:.2f} GB, "
                        f"BGZF level 1, {rb.n} records) + FASTA + BED -> basestrand.tsv ({out_bytes / 1e9:.2f} GB) on local disk, "
-                       f"process start to files closed; inflate on the host (16 threads), records found on the host, "
-                       f"packed on the device (bp_submit_bam), text rendered on the device",
+                       f"process start to files closed; BGZF inflated on the device (bp_inflate_blocks), records found on "
+                       f"the host, packed on the device (bp_submit_bam), text rendered on the device",
                "driver_stats": {"read_s": float(m.group(1)), "waiting_for_inflate_s": float(m.group(2)),
-                                "total_s": float(m.group(3))} if m else None,
+                                "device_inflate_kernels_s": float(m.group(3)), "total_s": float(m.group(4))} if m else None,
                "inputs_made_in_s": round(make_s, 1)}
         for pth in (outp, bam):
             os.remove(pth)
@@ -228,6 +228,35 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
                           "sample": f"first {sample_bp / 1e6:.0f} Mb ({hi} records, {os.path.getsize(sbam) / 1e9:.2f} GB BAM): "
                                     f"BGZF inflate + record decode (oracle/bam_decode.c, zlib) {dec_s:.1f} s, then rows "
                                     f"(oracle/pileup_oracle.c) - {cpu_s:.1f} s in all, 1 thread, no text output"}
+            # ... and on all host cores of the box's share: the whole contig as T position ranges,
+            # one BAM and one thread each (independent jobs with a read halo, like the reference's,
+            # pileup.go:862-932), every thread inflating + decoding its file and piling up its range
+            if not o.Stitch:
+                from concurrent.futures import ThreadPoolExecutor
+                T = min(16, os.cpu_count() or 1)
+                edges = [L * i // T for i in range(T + 1)]
+                parts = []
+                for i in range(T):
+                    a = int(np.searchsorted(rb.pos, max(0, edges[i] - 1024), "left"))
+                    b = int(np.searchsorted(rb.pos, edges[i + 1], "left"))
+                    pth = os.path.join(d, f"part{i}.bam")
+                    host.bam_write(pth, ["chr1"], [L], rb.slice(a, b), level=1, threads=16)
+                    parts.append(pth)
+
+                def one(i):
+                    prb, _ = O.bam_decode(parts[i])
+                    _, _, v = O.pileup(oopts, [L], {0: [[edges[i], edges[i + 1]]]}, prb, parallelism=1)
+                    return v.sum(axis=0, dtype=np.uint64)
+                tc = time.perf_counter()
+                with ThreadPoolExecutor(T) as ex:
+                    tot = sum(ex.map(one, range(T)))
+                mt_s = time.perf_counter() - tc
+                if [int(x) for x in tot] != job.column_sums():
+                    raise SystemExit("e2e: column sums of the multi-threaded CPU run differ from the device's")
+                blk["cpu"]["all_cores"] = {"value": round(B / mt_s / 1e9, 4), "unit": "Gbase/s", "cores": T,
+                                           "sample": f"the whole contig as {T} position ranges, one BAM and one thread each "
+                                                     f"(BGZF inflate + record decode + rows), in {mt_s:.1f} s; all 11 column sums "
+                                                     f"equal the device's"}
         return blk
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -234,8 +234,43 @@ struct BamReader::Impl {
   // One batch of BGZF blocks goes through two stages off the main thread, each a batch ahead of
   // the next: its bytes are read from the file and its block headers parsed (one thread: a memcpy
   // out of the page cache, a third of a second per GB), then its blocks are inflated (all threads).
+  // File bytes of a batch: pinned memory when the device inflates them (it copies them itself then,
+  // at the bus rate, instead of through the runtime's staging), grown like a vector.
+  struct RawBytes {
+    uint8_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    ~RawBytes() { drop(); }
+    void drop() {
+      if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+      p = nullptr;
+      n = cap = 0;
+    }
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+    void resize(size_t m, bool want_pinned) {
+      if (m > cap || (want_pinned && !pinned && cap)) {
+        const size_t ncap = std::max(m + m / 8 + 4096, cap);
+        uint8_t* q = nullptr;
+        bool pin = false;
+        if (want_pinned) {
+          void* hp = nullptr;
+          if (hipHostMalloc(&hp, ncap, hipHostMallocPortable) == hipSuccess) { q = (uint8_t*)hp; pin = true; }
+          else (void)hipGetLastError();
+        }
+        if (!q) q = (uint8_t*)malloc(ncap);
+        if (!q) throw std::bad_alloc();
+        if (n) memcpy(q, p, n);
+        const size_t keep = n;
+        drop();
+        p = q; cap = ncap; pinned = pin; n = keep;
+      }
+      n = m;
+    }
+  };
   struct RawBatch {
-    std::vector<uint8_t, NoInitAlloc<uint8_t>> raw;  // file bytes from `at` on
+    RawBytes raw;  // file bytes from `at` on
     struct Blk { size_t off, clen, isize, out; };    // deflate data at raw[off, off + clen), crc32 behind it; inflates to `out`
     std::vector<Blk> blks;
     std::vector<std::pair<size_t, uint64_t>> marks;  // (offset in the inflated buffer, file offset)
@@ -287,7 +322,7 @@ struct BamReader::Impl {
     size_t have = 0;
     bool file_end = false;
     auto read_more = [&](size_t want) {  // appends up to `want` file bytes
-      if (B.raw.size() < have + want) B.raw.resize(have + want);
+      if (B.raw.size() < have + want) B.raw.resize(have + want, pinned && inflate_device >= 0);
       while (want && !file_end) {
         ssize_t got = pread(fd, B.raw.data() + have, want, (off_t)(at + have));
         if (got < 0) { B.err = "bgzf: read failed"; file_end = true; break; }

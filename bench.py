@@ -195,7 +195,7 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
             fld = ln.split(b"\t")
             if int(fld[1]) != i + 1 or [int(x) for x in fld[3:11]] != dv[i][1:9].tolist() or fld[2] != bytes(seq[i:i + 1]):
                 raise SystemExit(f"e2e: line {i + 2} of the output differs from the device rows")
-        m = re.search(r"read_s=([0-9.]+).*waiting for inflated blocks ([0-9.]+).*device_inflate_s=([0-9.]+) total_s=([0-9.]+)", r.stderr)
+        m = re.search(r"read_s=([0-9.]+).*waiting for inflated blocks ([0-9.]+).*device_inflate_s=([0-9.]+).*total_s=([0-9.]+)", r.stderr)
         blk = {"value": round(B / wall / 1e9, 3), "unit": "Gbase/s", "wall_s": round(wall, 2),
                "what": f"bio-pileup {' '.join(x for x in flags if not x.startswith('/'))}: BAM ({os.path.getsize(bam) / 1e9:.2f} GB, "
                        f"BGZF level 1, {rb.n} records) + FASTA + BED -> basestrand.tsv ({out_bytes / 1e9:.2f} GB) on local disk, "

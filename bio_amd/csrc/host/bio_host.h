@@ -117,6 +117,9 @@ class BamReader {
   void SetDeviceInflate(int device);
   // Seconds the device spent in the inflate + CRC kernels, and bytes they produced.
   double DeviceInflateSeconds() const;
+  // Wall seconds of the read-ahead stages: file reads + header parse, inflate (either kind), and of that
+  // the time spent getting output buffers.
+  void StageSeconds(double* read_raw, double* inflate, double* take) const;
   // True when the next Next() has to bring in more of the file first: the buffers move then,
   // and the pointers of Raw records handed out so far stop being valid.
   bool NextRefills() const;

@@ -680,6 +680,9 @@ __device__ __forceinline__ void process_ov_group(const KernelParams& P, SH& B, c
   for (int k = 0; k < 8; k++) {
     const uint32_t c = (cw >> (4 * k)) & 7u;
     const uint32_t val = (vmask >> k) & 1u;
+#ifdef BP_X_NOATOMIC
+    if (val > 1u)
+#endif
     atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + G.lds_off + k * kSub * 4), val);
   }
 }
@@ -733,6 +736,9 @@ __device__ __forceinline__ void process_unit_plain(SH& B, const UnitLoad<QM, fal
       for (int k = 0; k < 8; k++) {
         const uint32_t c = (cw >> (4 * k)) & 7u;
         const uint32_t val = (vmask >> (8 * m + k)) & 1u;
+#ifdef BP_X_NOATOMIC
+        if (val > 1u)
+#endif
         atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + cbase + (8 * m + k) * kSub * 4), val);
       }
     }

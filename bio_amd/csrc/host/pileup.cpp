@@ -102,8 +102,30 @@ struct JobRows {
 struct Stream {  // one output stream = one strand pass (pileup.go:1118-1128)
   int strand_req = BP_STRAND_NONE;
   std::unique_ptr<RowWriter> writer;
+  // -per-strand in ONE pass: a split-strand job (strand_req none, counts by strand) feeds both
+  // files, `writer` the forward strand's and `writer_rev` the reverse strand's; each takes its
+  // strand's share of the rows (Depth = the strand's counts summed: exact while no base fails a
+  // quality rule, so only without -min-base-qual; and without -stitch, where a pair of reads on
+  // different strands would be stitched here and piled up alone in each of the reference's passes)
+  std::unique_ptr<RowWriter> writer_rev;
   bp_handle* h = nullptr;
 };
+
+// One strand's share of split-strand rows, as a -per-strand pass has them (format tsv: every count
+// in slot 0): n rows of BP_ROW_U32 in place.
+void StrandShare(uint32_t* vals, int64_t n, int s) {
+  for (int64_t i = 0; i < n; i++) {
+    uint32_t* r = vals + i * BP_ROW_U32;
+    uint32_t d = 0;
+    for (int b = 0; b < 5; b++) {
+      const uint32_t c = r[1 + 2 * b + s];
+      r[1 + 2 * b] = c;
+      r[2 + 2 * b] = 0;
+      d += c;
+    }
+    r[0] = d;
+  }
+}
 
 std::string HandleErr(bp_handle* h) { return bp_last_error(h); }
 
@@ -156,7 +178,7 @@ class Driver {
       bo.max_read_span = opts_.MaxReadSpan;
       bo.min_base_qual = opts_.MinBaseQual;
       bo.stitch = opts_.Stitch;
-      bo.ignore_strand = ignore_strand_;
+      bo.ignore_strand = s.writer_rev ? 0 : ignore_strand_;
       bo.strand_req = s.strand_req;
       bo.device = DeviceFor(j.seq);
       if (bp_create(&bo, (int32_t)hd_.ref_lens.size(), hd_.ref_lens.data(), names.data(), &s.h) != BP_OK)
@@ -261,15 +283,21 @@ class Driver {
       for (int64_t first = jr.row_lo; first < jr.row_hi; first += kRowChunk) {
         const int64_t m = std::min<int64_t>(kRowChunk, jr.row_hi - first);
         // basestrand-tsv: one file; tsv: the .ref.tsv and the .alt.tsv lines of the same rows
-        for (int which = 0; which < (text_tsv ? 2 : 1); which++) {
-          const int32_t kind = text_tsv ? (which == 0 ? BP_TEXT_TSV_REF : BP_TEXT_TSV_ALT) : BP_TEXT_BASESTRAND;
-          size_t len = 0;
-          if (bp_render_text(h, kind, text_cols, first, m, nullptr, 0, &len) != BP_OK) return HandleErr(h);
-          std::string text = streams[si].writer->SpareText(which);
-          text.resize(len);
-          if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
-          std::string err = streams[si].writer->WriteText(which, std::move(text));
-          if (!err.empty()) return err;
+        // (one-pass -per-strand: of each strand's share of them)
+        const bool split = streams[si].writer_rev != nullptr;
+        for (int strand = 0; strand < (split ? 2 : 1); strand++) {
+          RowWriter* w = strand ? streams[si].writer_rev.get() : streams[si].writer.get();
+          const int32_t sel = split ? (strand ? BP_TEXT_STRAND_REV : BP_TEXT_STRAND_FWD) : 0;
+          for (int which = 0; which < (text_tsv ? 2 : 1); which++) {
+            const int32_t kind = text_tsv ? (which == 0 ? BP_TEXT_TSV_REF : BP_TEXT_TSV_ALT) : BP_TEXT_BASESTRAND;
+            size_t len = 0;
+            if (bp_render_text(h, kind | sel, text_cols, first, m, nullptr, 0, &len) != BP_OK) return HandleErr(h);
+            std::string text = w->SpareText(which);
+            text.resize(len);
+            if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
+            std::string err = w->WriteText(which, std::move(text));
+            if (!err.empty()) return err;
+          }
         }
       }
     }
@@ -292,6 +320,13 @@ class Driver {
         if (first + chunk < n)
           next = std::thread([&, first] { Fetch(h, j, first + chunk, std::min(chunk, n - first - chunk), &buf[cur ^ 1]); });
         std::string err = c.err;
+        if (err.empty() && c.lo < c.hi && streams[si].writer_rev) {
+          // one-pass -per-strand (never with per-read columns): each file its strand's share
+          std::vector<uint32_t> share(c.vals.begin() + c.lo * BP_ROW_U32, c.vals.begin() + c.hi * BP_ROW_U32);
+          StrandShare(share.data(), c.hi - c.lo, 1);
+          err = streams[si].writer_rev->Write(c.ref.data() + c.lo, c.pos.data() + c.lo, share.data(), c.hi - c.lo, nullptr, nullptr);
+          StrandShare(c.vals.data() + c.lo * BP_ROW_U32, c.hi - c.lo, 0);
+        }
         if (err.empty() && c.lo < c.hi)
           err = streams[si].writer->Write(c.ref.data() + c.lo, c.pos.data() + c.lo, c.vals.data() + c.lo * BP_ROW_U32,
                                           c.hi - c.lo, per_read ? c.off.data() : nullptr,
@@ -604,20 +639,34 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   drv.text_tsv = tsv_format;
   drv.text_cols = cols & (kColDpRef | kColDpAlt | kColHighQ | kColLowQ);
   drv.ref_seqs = &ref_seqs;
-  const int n_stream = opts.PerStrand ? 2 : 1;
+  // -per-strand: the reference runs pileupSNPMain twice, forward reads then reverse reads
+  // (pileup.go:1118-1125).  Here one split-strand pass yields both files when that is exact (see
+  // Stream::writer_rev; BIO_PILEUP_TWO_PASS=1 keeps two handles fed side by side, as before round 3);
+  // otherwise two handles are fed the same records side by side.
+  const char* two_pass_env = getenv("BIO_PILEUP_TWO_PASS");
+  const bool one_pass = opts.PerStrand && opts.MinBaseQual == 0 && !opts.Stitch && !per_read &&
+                        !(two_pass_env && *two_pass_env && *two_pass_env != '0');
+  const int n_stream = opts.PerStrand && !one_pass ? 2 : 1;
   drv.streams.resize((size_t)n_stream);
+  const bool bgz = fmt == kTsvBgz || fmt == kBsTsvBgz;
+  auto new_writer = [&](const std::string& path, std::string* err) {
+    return tsv_format ? NewTsvWriter(path, cols, bgz, hd.ref_names, ref_seqs, err)
+                      : NewBasestrandTsvWriter(path, cols, bgz, hd.ref_names, ref_seqs, err);
+  };
   for (int s = 0; s < n_stream; s++) {
     Stream& st = drv.streams[(size_t)s];
     std::string main_path = out_prefix;
     if (opts.PerStrand) {
-      st.strand_req = s == 0 ? BP_STRAND_FWD : BP_STRAND_REV;
+      if (!one_pass) st.strand_req = s == 0 ? BP_STRAND_FWD : BP_STRAND_REV;
       main_path += s == 0 ? ".strand.fwd" : ".strand.rev";
     }
     std::string err;
-    const bool bgz = fmt == kTsvBgz || fmt == kBsTsvBgz;
-    st.writer = tsv_format ? NewTsvWriter(main_path, cols, bgz, hd.ref_names, ref_seqs, &err)
-                           : NewBasestrandTsvWriter(main_path, cols, bgz, hd.ref_names, ref_seqs, &err);
+    st.writer = new_writer(main_path, &err);
     if (!err.empty()) return err;
+    if (one_pass) {
+      st.writer_rev = new_writer(out_prefix + ".strand.rev", &err);
+      if (!err.empty()) return err;
+    }
   }
 
   // 5. jobs: BED-covered ranges of each contig, at most JobSpan() positions each
@@ -918,6 +967,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   for (Stream& s : drv.streams) {
     std::string e = s.writer->Close();
     if (!e.empty()) return e;
+    if (s.writer_rev && !(e = s.writer_rev->Close()).empty()) return e;
   }
   st.total_s = Now() - t_start;
   double sr = 0, si = 0, stk = 0;

@@ -1886,6 +1886,7 @@ int bp_set_ref_seq8(bp_handle* h, int32_t ref_id, int32_t start, const uint8_t* 
 }
 
 int64_t bp_render_text_bound(const bp_handle* h, int32_t kind, int64_t n_rows) {
+  kind &= 0xff;  // (the strand flags do not change the bound)
   if (!h || h->seq_ref < 0 || n_rows < 0 || kind < 0 || kind > 2) return -1;
   const size_t nm = (size_t)h->seq_ref < h->ref_name.size() ? h->ref_name[(size_t)h->seq_ref].size() : 0;
   const size_t head = nm + 1 + 11 + 2;
@@ -1897,7 +1898,11 @@ int64_t bp_render_text_bound(const bp_handle* h, int32_t kind, int64_t n_rows) {
 int bp_render_text(bp_handle* h, int32_t kind, int32_t cols, int64_t first, int64_t n, char* out, size_t cap,
                    size_t* len) {
   if (!h || !len) return fail(h, BP_EINVAL, "bp_render_text: null argument");
-  if (kind < 0 || kind > 2) return fail(h, BP_EINVAL, "bp_render_text: kind %d", kind);
+  const int32_t strand = (kind >> 8) & 3;
+  kind &= 0xff;
+  if (kind < 0 || kind > 2 || strand == 3) return fail(h, BP_EINVAL, "bp_render_text: kind %d", kind);
+  if (strand && (h->o.ignore_strand || h->o.strand_req || h->o.min_base_qual > 0))
+    return fail(h, BP_EINVAL, "bp_render_text: one strand's lines come from split-strand rows of a job without a quality rule");
   if (cols & ~(BP_COL_DPREF | BP_COL_DPALT | BP_COL_HIGHQ | BP_COL_LOWQ))
     return fail(h, BP_EINVAL, "bp_render_text: per-read columns are not rendered on the device");
   if (!h->rows_valid) return fail(h, BP_EINVAL, "bp_render_text: no computed rows (call bp_finish)");
@@ -1944,6 +1949,7 @@ int bp_render_text(bp_handle* h, int32_t kind, int32_t cols, int64_t first, int6
   T.name_len = (int32_t)((size_t)h->seq_ref < h->ref_name.size() ? h->ref_name[(size_t)h->seq_ref].size() : 0);
   T.kind = kind;
   T.cols = cols;
+  T.strand = strand;
   launch_text(T, h->stream);
   launch_text_write(T, h->stream);
   HIP_TRY(h, hipGetLastError());

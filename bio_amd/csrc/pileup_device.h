@@ -182,6 +182,7 @@ struct TextParams {
   int64_t seq_len;
   int32_t n_iv, seq_ref, seq_start, name_len;
   int32_t kind, cols;        // BP_TEXT_* and the -cols bit set (bio_pileup.h)
+  int32_t strand;            // 0: the rows as they are; 1 / 2: the forward / reverse strand's share of split-strand rows
 };
 
 }  // namespace bp

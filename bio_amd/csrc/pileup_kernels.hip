@@ -1951,6 +1951,29 @@ __device__ __forceinline__ void text_row_write(const TextParams& T, char* p, int
   }
 }
 
+// A row as the text is made from: with T.strand set, one strand's share of a split-strand row -
+// what a -per-strand pass of the reference holds for that strand (pileup.go:718-723, :1118-1125:
+// only that strand's reads are piled up, format tsv puts every count in slot 0): the strand's
+// counts in slot 0, Depth = their sum (exact while no base fails the quality rule: such bases
+// count in Depth only and are not in the row; the host asks for this only with min_base_qual 0).
+__device__ __forceinline__ void text_load_row(const TextParams& T, int64_t i, uint32_t (&r)[11]) {
+  const uint32_t* src = T.rows + i * 11;
+#pragma unroll
+  for (int k = 0; k < 11; k++) r[k] = src[k];
+  if (T.strand) {
+    const int s = T.strand - 1;
+    uint32_t d = 0;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+      const uint32_t c = r[1 + 2 * b + s];
+      r[1 + 2 * b] = c;
+      r[2 + 2 * b] = 0;
+      d += c;
+    }
+    r[0] = d;
+  }
+}
+
 // line lengths, scanned inside tiles of 1024 rows
 __global__ __launch_bounds__(256) void text_len_kernel(TextParams T) {
   __shared__ uint32_t sh[256];
@@ -1964,7 +1987,11 @@ __global__ __launch_bounds__(256) void text_len_kernel(TextParams T) {
       int32_t ref, pos;
       text_row_pos(T, T.first + i, ref, pos);
       if (ref != T.seq_ref || pos < T.seq_start || (int64_t)pos - T.seq_start >= T.seq_len) *T.bad = 1;
-      else v[k] = text_row_len(T, pos, T.rows + (T.first + i) * 11, T.seq8[pos - T.seq_start] & 15u);
+      else {
+        uint32_t r[11];
+        text_load_row(T, T.first + i, r);
+        v[k] = text_row_len(T, pos, r, T.seq8[pos - T.seq_start] & 15u);
+      }
     }
     s += v[k];
   }
@@ -2027,8 +2054,9 @@ __global__ void text_write_kernel(TextParams T) {
   int32_t ref, pos;
   text_row_pos(T, T.first + i, ref, pos);
   if (ref != T.seq_ref || pos < T.seq_start || (int64_t)pos - T.seq_start >= T.seq_len) return;
-  text_row_write(T, T.out + T.tile[i >> 10] + T.len[i], pos, T.rows + (T.first + i) * 11,
-                 T.seq8[pos - T.seq_start] & 15u);
+  uint32_t r[11];
+  text_load_row(T, T.first + i, r);
+  text_row_write(T, T.out + T.tile[i >> 10] + T.len[i], pos, r, T.seq8[pos - T.seq_start] & 15u);
 }
 
 void launch_text(const TextParams& T, hipStream_t s) {

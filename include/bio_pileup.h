@@ -246,8 +246,12 @@ int bp_per_read_features(bp_handle* h, uint64_t first, uint64_t n, bp_per_read* 
  * bp_render_fetch copies it to a buffer of that size.  REF comes from the Seq8 bases
  * (encoding/fasta/fasta.go:50-62) given by bp_set_ref_seq8 for ONE reference, positions
  * [start, start+n): every rendered row must lie there (the reference indexes refSeqs[refID][pos],
- * output.go:158).  <chrom> is the ref_name given to bp_create. */
-enum { BP_TEXT_BASESTRAND = 0, BP_TEXT_TSV_REF = 1, BP_TEXT_TSV_ALT = 2 };
+ * output.go:158).  <chrom> is the ref_name given to bp_create.
+ * BP_TEXT_STRAND_FWD / _REV, or-ed into `kind`: the lines of ONE strand's -per-strand pass
+ * (pileup.go:718-723, :1118-1125) from the split-strand rows of a single pass: that strand's counts
+ * as the row's counts and their sum as DP.  Only for jobs without a quality rule (min_base_qual
+ * 0, no stitching), where every base is in a count slot; refused otherwise. */
+enum { BP_TEXT_BASESTRAND = 0, BP_TEXT_TSV_REF = 1, BP_TEXT_TSV_ALT = 2, BP_TEXT_STRAND_FWD = 0x100, BP_TEXT_STRAND_REV = 0x200 };
 enum { BP_COL_DPREF = 1, BP_COL_DPALT = 2, BP_COL_HIGHQ = 64, BP_COL_LOWQ = 128 };
 int bp_set_ref_seq8(bp_handle* h, int32_t ref_id, int32_t start, const uint8_t* seq8, int64_t n);
 int64_t bp_render_text_bound(const bp_handle* h, int32_t kind, int64_t n_rows);

@@ -324,6 +324,34 @@ def test_per_strand(tmp_path):
         assert c.read("ps" + sfx + ".alt.tsv") == wa
 
 
+def test_per_strand_in_one_pass(tmp_path, monkeypatch):
+    """-per-strand without -stitch and -min-base-qual: ONE split-strand pass yields both files
+    (each strand's share of the rows).  Both equal the oracle's two passes (pileup.go:1118-1125),
+    through the device's text and the host's, and the two-handle path (BIO_PILEUP_TWO_PASS=1)
+    writes the same bytes.  Mapq 0 keeps the reads with odd flags in."""
+    c = Case(tmp_path, seed=19)
+    for cols, mask in (("", host.COLS_DEFAULT), ("dpref,dpalt,highq", host.COL_DPREF | host.COL_DPALT | host.COL_HIGHQ)):
+        got = {}
+        for mode in ("device", "host_text", "two_pass"):
+            monkeypatch.delenv("BIO_PILEUP_HOST_TEXT", raising=False)
+            monkeypatch.delenv("BIO_PILEUP_TWO_PASS", raising=False)
+            if mode == "host_text":
+                monkeypatch.setenv("BIO_PILEUP_HOST_TEXT", "1")
+            if mode == "two_pass":
+                monkeypatch.setenv("BIO_PILEUP_TWO_PASS", "1")
+            out = str(tmp_path / f"p1_{mode}")
+            host.pileup(c.bam, c.fa, "tsv", out, Opts(BedPath=c.bed_path, PerStrand=True, Mapq=0, Cols=cols))
+            got[mode] = [c.read(f"p1_{mode}{sfx}.{f}.tsv") for sfx in (".strand.fwd", ".strand.rev") for f in ("ref", "alt")]
+        want = []
+        for req in (1, 2):
+            rows = c.oracle(mapq=0, ignore_strand=1, strand_req=req)
+            want += list(render_tsv(rows, c.ref_names, c.ref_ascii, mask))
+        assert got["device"] == want
+        assert got["host_text"] == want
+        assert got["two_pass"] == want
+    assert want[0] != want[2]  # the strands do differ
+
+
 def test_region_mode(tmp_path):
     """-region: one unpadded shard (pileup.go:1091-1096) - reads starting before the region
     are never seen; a contig-only region is clamped to the contig (documented divergence)."""

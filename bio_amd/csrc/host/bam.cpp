@@ -26,6 +26,40 @@
 
 namespace bio {
 
+constexpr size_t kTextPinFrom = 8u << 20;  // (the host renderer's pieces stay below it)
+void* TextAlloc(size_t n) {
+  void* p = nullptr;
+  if (n >= kTextPinFrom) {
+    if (hipHostMalloc(&p, n, hipHostMallocPortable) == hipSuccess) return p;
+    (void)hipGetLastError();
+    // (no device, or no pinned memory left: plain memory does; TextFree tells the two apart)
+    p = nullptr;
+  }
+  p = malloc(n + (n >= kTextPinFrom ? 16 : 0));
+  if (!p) throw std::bad_alloc();
+  if (n >= kTextPinFrom) {
+    // a large block that is NOT pinned carries a mark in front
+    memcpy(p, "notpinned-block", 16);
+    return (char*)p + 16;
+  }
+  return p;
+}
+void TextFree(void* p, size_t n) {
+  if (!p) return;
+  if (n >= kTextPinFrom) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost) {
+      (void)hipHostFree(p);
+      return;
+    }
+    (void)hipGetLastError();
+    free((char*)p - 16);
+    return;
+  }
+  free(p);
+}
+
 namespace {
 inline uint16_t U16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t U32(const uint8_t* p) {

@@ -224,6 +224,23 @@ int BioPileupMain(int argc, char** argv);
 
 // ---------------------------------------------------------------- output (output.go)
 // Row sink used by Pileup: rows arrive in ascending (ref,pos) order.
+// Text that the device has rendered comes to the host in strings whose large buffers are pinned
+// memory (hipHostMalloc): the copy from the device then runs at the bus rate instead of through
+// the runtime's staging buffers, which was half of a closer thread's time.  Small strings use malloc.
+void* TextAlloc(size_t n);
+void TextFree(void* p, size_t n);
+template <class T>
+struct TextAllocator {
+  using value_type = T;
+  TextAllocator() = default;
+  template <class U> TextAllocator(const TextAllocator<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(TextAlloc(n * sizeof(T))); }
+  void deallocate(T* p, size_t n) { TextFree(p, n * sizeof(T)); }
+  template <class U> bool operator==(const TextAllocator<U>&) const { return true; }
+  template <class U> bool operator!=(const TextAllocator<U>&) const { return false; }
+};
+using TextString = std::basic_string<char, std::char_traits<char>, TextAllocator<char>>;
+
 class RowWriter {
  public:
   virtual ~RowWriter() {}
@@ -235,8 +252,8 @@ class RowWriter {
   // `which` of the format (basestrand-tsv: 0; tsv: 0 = .ref.tsv, 1 = .alt.tsv).
   // SpareText: a string to render into, one the sink has finished with (capacity kept, no fresh
   // pages) if there is one.
-  virtual std::string SpareText(int which) { (void)which; return std::string(); }
-  virtual std::string WriteText(int which, std::string&& text) {
+  virtual TextString SpareText(int which) { (void)which; return TextString(); }
+  virtual std::string WriteText(int which, TextString&& text) {
     (void)which; (void)text;
     return "pileup output: this format takes rows, not text";
   }

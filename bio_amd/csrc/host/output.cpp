@@ -76,7 +76,7 @@ class Sink {
   // Text is handed to a thread of the sink's own (file writes and BGZF compression then
   // overlap the rendering of the next rows); at most kMaxQueued bytes wait.  An error of an
   // earlier write comes back from a later call or from Close.
-  std::string Write(std::string&& text) {
+  std::string Write(TextString&& text) {
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [this] { return queued_ < kMaxQueued || !err_.empty(); });
     if (!err_.empty()) return err_;
@@ -85,11 +85,11 @@ class Sink {
     cv_.notify_all();
     return "";
   }
-  std::string Write(const char* p, size_t n) { return Write(std::string(p, n)); }
-  std::string Spare() {
+  std::string Write(const char* p, size_t n) { return Write(TextString(p, n)); }
+  TextString Spare() {
     std::unique_lock<std::mutex> lk(mu_);
-    if (spare_.empty()) return std::string();
-    std::string s = std::move(spare_.back());
+    if (spare_.empty()) return TextString();
+    TextString s = std::move(spare_.back());
     spare_.pop_back();
     return s;
   }
@@ -119,7 +119,7 @@ class Sink {
   }
   void Run() {
     for (;;) {
-      std::string text;
+      TextString text;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return !q_.empty() || done_; });
@@ -131,7 +131,8 @@ class Sink {
       std::unique_lock<std::mutex> lk(mu_);
       queued_ -= text.size();
       if (spare_.size() < 4 && text.capacity() >= (1u << 20)) {  // large buffers go round again
-        text.clear();
+        // (with their old contents: whoever takes one sets its size, and growing a string fills it -
+        // 34 MB of zeros per chunk of rows were a third of a closer's time)
         spare_.push_back(std::move(text));
       }
       if (err_.empty() && !e.empty()) err_ = e;
@@ -175,8 +176,8 @@ class Sink {
   }
   std::mutex mu_;
   std::condition_variable cv_;
-  std::deque<std::string> q_;
-  std::vector<std::string> spare_;
+  std::deque<TextString> q_;
+  std::vector<TextString> spare_;
   size_t queued_ = 0;
   bool done_ = false;
   std::string err_;
@@ -291,8 +292,9 @@ class Tsv {
     line_.str().clear();
     return err;
   }
-  std::string Append(std::string&& text) { return sink_.Write(std::move(text)); }
-  std::string Spare() { return sink_.Spare(); }
+  std::string Append(TextString&& text) { return sink_.Write(std::move(text)); }
+  std::string Append(std::string&& text) { return sink_.Write(text.data(), text.size()); }
+  TextString Spare() { return sink_.Spare(); }
   std::string Close() { return sink_.Close(); }
 
  private:
@@ -391,8 +393,8 @@ class TsvWriter : public RowWriter {
       w.EndCsv();
     }
   }
-  std::string SpareText(int which) override { return which == 0 ? ref_.Spare() : alt_.Spare(); }
-  std::string WriteText(int which, std::string&& text) override {
+  TextString SpareText(int which) override { return which == 0 ? ref_.Spare() : alt_.Spare(); }
+  std::string WriteText(int which, TextString&& text) override {
     if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
     return which == 0 ? ref_.Append(std::move(text)) : alt_.Append(std::move(text));
   }
@@ -517,8 +519,8 @@ class BasestrandTsvWriter : public RowWriter {
     }
   }
   static void AppendUint(std::string& s, uint32_t v) { s += std::to_string(v); s.push_back(','); }
-  std::string SpareText(int) override { return w_.Spare(); }
-  std::string WriteText(int, std::string&& text) override {
+  TextString SpareText(int) override { return w_.Spare(); }
+  std::string WriteText(int, TextString&& text) override {
     if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
     return w_.Append(std::move(text));
   }

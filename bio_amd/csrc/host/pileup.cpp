@@ -292,7 +292,7 @@ class Driver {
             const int32_t kind = text_tsv ? (which == 0 ? BP_TEXT_TSV_REF : BP_TEXT_TSV_ALT) : BP_TEXT_BASESTRAND;
             size_t len = 0;
             if (bp_render_text(h, kind | sel, text_cols, first, m, nullptr, 0, &len) != BP_OK) return HandleErr(h);
-            std::string text = w->SpareText(which);
+            TextString text = w->SpareText(which);
             text.resize(len);
             if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
             std::string err = w->WriteText(which, std::move(text));

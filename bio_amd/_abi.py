@@ -71,7 +71,7 @@ EXPORTS = [
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
     "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch",
     "bp_inflate_create", "bp_inflate_destroy", "bp_inflate_blocks", "bp_inflate_device_output", "bp_inflate_stream",
-    "bp_inflate_timing", "bp_inflate_last_error",
+    "bp_inflate_timing", "bp_inflate_last_error", "bp_bam_scan", "bp_submit_bam_device",
 ]
 
 HOST_EXPORTS = [
@@ -112,6 +112,13 @@ class bio_pileup_opts(C.Structure):
 class bp_bgzf_block(C.Structure):
     _fields_ = [("in_off", C.c_uint32), ("in_len", C.c_uint32), ("out_off", C.c_uint32), ("out_len", C.c_uint32),
                 ("crc32", C.c_uint32)]
+
+
+class bp_bam_columns(C.Structure):
+    _fields_ = [("cap", C.c_int64), ("off", C.c_void_p), ("ref_id", C.c_void_p), ("pos", C.c_void_p),
+                ("mate_ref_id", C.c_void_p), ("mate_pos", C.c_void_p), ("flags", C.c_void_p), ("mapq", C.c_void_p),
+                ("l_name", C.c_void_p), ("n_cigar", C.c_void_p), ("l_seq", C.c_void_p), ("bytes", C.c_void_p),
+                ("span", C.c_void_p), ("facts", C.c_void_p)]
 
 
 class bio_basestrand_tsv_row(C.Structure):
@@ -211,6 +218,11 @@ def load():
     lib.bp_inflate_timing.restype = C.c_int
     lib.bp_inflate_last_error.argtypes = [H]
     lib.bp_inflate_last_error.restype = C.c_char_p
+    lib.bp_bam_scan.argtypes = [H, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(bp_bam_columns),
+                                C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    lib.bp_bam_scan.restype = C.c_int
+    lib.bp_submit_bam_device.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(bp_bam_columns), C.c_int64, C.c_int64]
+    lib.bp_submit_bam_device.restype = C.c_int
     # include/bio_pileup_host.h
     E = [C.c_char_p, C.c_size_t]
     lib.bio_pileup_default_opts.argtypes = [C.POINTER(bio_pileup_opts)]

@@ -70,6 +70,29 @@ class Inflater:
             raise PileupError(rc, self.lib.bp_inflate_last_error(self.h).decode())
         return out
 
+    COLS = (("off", np.uint32), ("ref_id", np.int32), ("pos", np.int32), ("mate_ref_id", np.int32), ("mate_pos", np.int32),
+            ("flags", np.uint16), ("mapq", np.uint8), ("l_name", np.uint8), ("n_cigar", np.uint32), ("l_seq", np.uint32),
+            ("bytes", np.uint32), ("span", np.int32), ("facts", np.uint8))
+
+    def scan(self, first, end, n_ref, cap=None, stream=None):
+        """bp_bam_scan over the last inflate's device output (or `stream`, a device address): ->
+        (rc, cols dict of numpy arrays cut to n, exit, stopped, the bp_bam_columns struct).  rc 1:
+        a guess failed (walk on the host)."""
+        if cap is None:
+            cap = (end - first) // 36 + 1
+        arrs = {k: np.zeros(cap, t) for k, t in self.COLS}
+        c = _abi.bp_bam_columns()
+        c.cap = cap
+        for k, _ in self.COLS:
+            setattr(c, k, arrs[k].ctypes.data)
+        n, ex, st = C.c_int64(), C.c_uint64(), C.c_int32()
+        rc = self.lib.bp_bam_scan(self.h, stream if stream is not None else self.device_output, first, end, n_ref,
+                                  C.byref(c), C.byref(n), C.byref(ex), C.byref(st))
+        if rc < 0:
+            raise PileupError(rc, self.lib.bp_inflate_last_error(self.h).decode())
+        self._keep = arrs
+        return rc, {k: v[:n.value] for k, v in arrs.items()}, ex.value, st.value, c
+
     def timing(self):
         a, b = C.c_float(), C.c_float()
         self.lib.bp_inflate_timing(self.h, C.byref(a), C.byref(b))

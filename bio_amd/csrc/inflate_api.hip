@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/bio_pileup.h"
+#include "bam_device.h"
 #include "inflate_device.h"
 
 namespace bp {
@@ -23,6 +24,10 @@ void launch_inflate(const uint8_t* comp, const InflateBlock* blks, int n_blocks,
                     hipStream_t s);
 void launch_bgzf_crc(const uint8_t* out, const InflateBlock* blks, int n_blocks, const uint32_t* crc_tables,
                      uint32_t* status, hipStream_t s);
+void launch_bam_scan(const uint8_t* buf, uint64_t lo, uint64_t end, int32_t n_ref, int32_t n_stretch, WalkStretch* ws,
+                     uint32_t* offs, uint32_t* out4, hipStream_t s);
+void launch_bam_fields(const uint8_t* buf, int32_t n_stretch, const WalkStretch* ws, const uint32_t* offs,
+                       const BamColumns& C, hipStream_t s);
 }
 using namespace bp;
 
@@ -41,6 +46,8 @@ struct bp_inflater {
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   Buf comp, blks, out, status;  // device
+  Buf walk, offs, cols;         // device: the record scan's stretches, offsets and columns
+  uint32_t* h_scan = nullptr;   // pinned: the verifier's four words
   uint32_t* tables = nullptr;   // device: CRC tables
   uint32_t* h_status = nullptr; // pinned
   size_t h_status_cap = 0;
@@ -146,7 +153,8 @@ void bp_inflate_destroy(bp_inflater* f) {
   if (!f) return;
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
-  for (Buf* b : {&f->comp, &f->blks, &f->out, &f->status})
+  if (f->h_scan) (void)hipHostFree(f->h_scan);
+  for (Buf* b : {&f->comp, &f->blks, &f->out, &f->status, &f->walk, &f->offs, &f->cols})
     if (b->p) (void)hipFree(b->p);
   if (f->tables) (void)hipFree(f->tables);
   if (f->h_status) (void)hipHostFree(f->h_status);
@@ -210,6 +218,79 @@ int bp_inflate_blocks(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, co
       if (bad_block) *bad_block = i;
       return ifail(f, BP_EDATA, "bgzf: corrupt block %lld (%s)", (long long)i, status_text(f->h_status[i]));
     }
+  return BP_OK;
+}
+
+int bp_bam_scan(bp_inflater* f, const uint8_t* stream, uint64_t first, uint64_t end, int32_t n_ref,
+                bp_bam_columns* cols, int64_t* n_out, uint64_t* exit_out, int32_t* stopped_out) {
+  if (!f || !stream || !cols || !n_out || !exit_out || !stopped_out || first > end || end > 0xfffffff0ull)
+    return ifail(f, BP_EINVAL, "bp_bam_scan: bad argument");
+  *n_out = 0;
+  *exit_out = first;
+  *stopped_out = 0;
+  if (first == end) return BP_OK;
+  INF_TRY(f, hipSetDevice(f->device));
+  const int32_t ns = (int32_t)((end - first + kStretch - 1) / kStretch);
+  if (int rc = grow(f, f->walk, (size_t)ns * sizeof(WalkStretch))) return rc;
+  if (int rc = grow(f, f->offs, (size_t)ns * kMaxPerStretch * 4)) return rc;
+  if (!f->h_scan) INF_TRY(f, hipHostMalloc((void**)&f->h_scan, 64, hipHostMallocDefault));
+  // 4 words of verdict live behind the stretches
+  if (int rc = grow(f, f->status, 64)) return rc;
+  uint32_t* d_out = (uint32_t*)f->status.p;
+  launch_bam_scan(stream, first, end, n_ref, ns, (WalkStretch*)f->walk.p, (uint32_t*)f->offs.p, d_out, f->stream);
+  INF_TRY(f, hipGetLastError());
+  INF_TRY(f, hipMemcpyAsync(f->h_scan, d_out, 16, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipStreamSynchronize(f->stream));
+  if (f->h_scan[0] != 0) {  // a guess failed: the host walks this stream
+    const uint32_t j = f->h_scan[0] - 1;
+    WalkStretch w[2] = {};
+    (void)hipMemcpy(w, (const WalkStretch*)f->walk.p + (j ? j - 1 : 0), sizeof(WalkStretch) * (j ? 2 : 1), hipMemcpyDeviceToHost);
+    const WalkStretch& cur = w[j ? 1 : 0];
+    ifail(f, 1, "bp_bam_scan: stretch %u of %d started at %u (flags %u, %u records) where the chain stands at %u (the stretch before: %u -> %u, %u records, flags %u)",
+          j, ns, cur.start, cur.flags, cur.n, f->h_scan[2], w[0].start, w[0].exit, w[0].n, w[0].flags);
+    return 1;
+  }
+  const int64_t n = (int64_t)f->h_scan[1];
+  if (n > cols->cap) return ifail(f, BP_ENOMEM, "bp_bam_scan: %lld records, room for %lld", (long long)n, (long long)cols->cap);
+  *n_out = n;
+  *exit_out = f->h_scan[2];
+  *stopped_out = (int32_t)f->h_scan[3];
+  if (n == 0) return BP_OK;
+  // device columns: one allocation, 48 bytes a record
+  const size_t N = ((size_t)n + 63) & ~(size_t)63;
+  if (int rc = grow(f, f->cols, N * 48)) return rc;
+  uint8_t* b = (uint8_t*)f->cols.p;
+  BamColumns C;
+  C.off = (uint32_t*)b;           b += 4 * N;
+  C.ref = (int32_t*)b;            b += 4 * N;
+  C.pos = (int32_t*)b;            b += 4 * N;
+  C.mref = (int32_t*)b;           b += 4 * N;
+  C.mpos = (int32_t*)b;           b += 4 * N;
+  C.ncig = (uint32_t*)b;          b += 4 * N;
+  C.lseq = (uint32_t*)b;          b += 4 * N;
+  C.bytes = (uint32_t*)b;         b += 4 * N;
+  C.span = (int32_t*)b;           b += 4 * N;
+  C.flags = (uint16_t*)b;         b += 2 * N;
+  C.mapq = b;                     b += N;
+  C.lname = b;                    b += N;
+  C.facts = b;
+  launch_bam_fields(stream, ns, (const WalkStretch*)f->walk.p, (const uint32_t*)f->offs.p, C, f->stream);
+  INF_TRY(f, hipGetLastError());
+  const size_t m = (size_t)n;
+  INF_TRY(f, hipMemcpyAsync(cols->off, C.off, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->ref_id, C.ref, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->pos, C.pos, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->mate_ref_id, C.mref, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->mate_pos, C.mpos, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->n_cigar, C.ncig, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->l_seq, C.lseq, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->bytes, C.bytes, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->span, C.span, 4 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->flags, C.flags, 2 * m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->mapq, C.mapq, m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->l_name, C.lname, m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(cols->facts, C.facts, m, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipStreamSynchronize(f->stream));
   return BP_OK;
 }
 

@@ -617,6 +617,7 @@ struct Src {
   const uint32_t *n_cigar = nullptr, *l_seq = nullptr;
   const bp_record_batch* b = nullptr;  // column mode: where the payloads are
   const uint8_t* raw = nullptr;        // stream mode: record i starts (block_size field) at raw + off[i]
+  const uint8_t* raw_dev = nullptr;    // ... or at raw_dev + off[i] in DEVICE memory (bp_submit_bam_device; no names, no host bytes)
   const uint32_t* off = nullptr;
   const uint8_t* l_name = nullptr;     // stream mode: l_read_name (with the NUL)
   const uint32_t* rec_bytes = nullptr; // stream mode: 4 + block_size
@@ -626,14 +627,26 @@ struct Src {
   const uint8_t* cigar(int64_t i) const {
     return raw ? raw + off[i] + 36 + l_name[i] : (const uint8_t*)(b->cigar + b->cigar_off[i]);
   }
-  bool has_names() const { return raw || (b->name && b->name_off); }
+  bool has_names() const { return raw || (b && b->name && b->name_off); }
   const uint8_t* name(int64_t i) const { return raw ? raw + off[i] + 36 : b->name + b->name_off[i]; }
   uint32_t name_len(int64_t i) const {
     return raw ? (l_name[i] ? l_name[i] - 1u : 0u) : (uint32_t)(b->name_off[i + 1] - b->name_off[i]);
   }
 };
 
+// a few bytes of a record that lies on the device (error paths only)
+std::vector<uint8_t> dev_bytes(const Src& S, int64_t i, size_t at, size_t n) {
+  std::vector<uint8_t> v(n, 0);
+  if (n && hipMemcpy(v.data(), S.raw_dev + S.off[i] + at, n, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+  return v;
+}
+
 std::string read_name(const Src& S, int64_t i) {
+  if (S.raw_dev) {
+    const size_t ln = S.l_name[i] ? S.l_name[i] - 1u : 0u;
+    const std::vector<uint8_t> v = dev_bytes(S, i, 36, ln);
+    return std::string((const char*)v.data(), ln);
+  }
   if (!S.has_names()) return std::string();
   return std::string((const char*)S.name(i), (size_t)S.name_len(i));
 }
@@ -809,7 +822,9 @@ int scan_slice(bp_handle* h, const Src& S, int64_t i0, int64_t i1, std::vector<i
     if (f & SC_BAD_OP) {
       // alignRelevantBases (pileup.go:355-359) fails at the first op outside MIDNSH that its
       // walk reaches, i.e. one starting before the end of the last overlapping interval.
-      const uint8_t* cg = S.cigar(i);
+      std::vector<uint8_t> cg_dev;
+      if (S.raw_dev) cg_dev = dev_bytes(S, i, 36 + (size_t)S.l_name[i], 4 * (size_t)S.n_cigar[i]);
+      const uint8_t* cg = S.raw_dev ? cg_dev.data() : S.cigar(i);
       const int32_t last_end = bed_last_overlap_end(h->bed[(size_t)ref], pos + span);
       int32_t rp = pos;
       for (uint32_t c = 0; c < S.n_cigar[i]; c++) {
@@ -1109,8 +1124,8 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
     }
   } poison{h};
   const int nthreads = pack_threads();
-  const bool stream_mode = S.raw != nullptr;
-  const bool pinned_src = stream_mode && S.n > 0 && host_pinned(S.raw + S.off[0]);
+  const bool stream_mode = S.raw != nullptr || S.raw_dev != nullptr;
+  const bool pinned_src = S.raw != nullptr && S.n > 0 && host_pinned(S.raw + S.off[0]);
   // a copy out of the caller's own memory is in flight: the caller's memory is the caller's again
   // when the call returns, however it returns
   bool wait_for_copy = false;
@@ -1207,14 +1222,19 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       if (extent > 0xffffffffull) return fail(h, BP_EINVAL, "%s: records spread over more than 4 GiB", who);
       uint64_t wanted = 0;
       for (int64_t i = i0; i < i1; i++) wanted += S.rec_bytes[i];
-      direct = pinned_src && wanted * 4 >= extent * 3;
+      direct = S.raw_dev != nullptr || (pinned_src && wanted * 4 >= extent * 3);
       {
         ProfTimer pt(&h->prof[5]);
         if (int rc = acquire_stage(h, &st, true, direct ? 0 : (size_t)wanted)) return rc;
-        if (int rc = ensure(h, h->d_raw, (size_t)(direct ? extent : wanted) + 64, 0)) return rc;
+        if (!S.raw_dev)
+          if (int rc = ensure(h, h->d_raw, (size_t)(direct ? extent : wanted) + 64, 0)) return rc;
         if (int rc = ensure(h, h->d_pack, ns * sizeof(PackItem), 0)) return rc;
       }
-      if (direct) {
+      if (S.raw_dev) {
+        // the records are on the device already: the pack kernel reads them where they lie, and the
+        // caller's buffer is the caller's again when the call returns (see CopyFence)
+        wait_for_copy = true;
+      } else if (direct) {
         HIP_TRY(h, hipMemcpyAsync(h->d_raw.p, S.raw + raw_first, (size_t)extent, hipMemcpyHostToDevice, h->stream));
         wait_for_copy = true;
       } else {
@@ -1274,7 +1294,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       h->pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
       h->prof[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
       HIP_TRY(h, hipMemcpyAsync(h->d_pack.p, st->items, ns * sizeof(PackItem), hipMemcpyHostToDevice, h->stream));
-      launch_pack((const uint8_t*)h->d_raw.p, (const PackItem*)h->d_pack.p, (int64_t)ns, (ReadCore*)h->d_cores.p + h->n_reads,
+      launch_pack(S.raw_dev ? S.raw_dev + raw_first : (const uint8_t*)h->d_raw.p, (const PackItem*)h->d_pack.p, (int64_t)ns, (ReadCore*)h->d_cores.p + h->n_reads,
                   (uint8_t*)h->d_blob.p, h->qpass ? 1 : 0, h->o.min_base_qual, h->o.clip, h->stream);
       HIP_TRY(h, hipGetLastError());
     } else {
@@ -1475,6 +1495,53 @@ int bp_submit_bam(bp_handle* h, const uint8_t* bam, size_t n_bytes, const uint32
     return fail(h, BP_ENOMEM, "bp_submit_bam: out of host memory");
   } catch (const std::exception& ex) {
     return fail(h, BP_ENOMEM, "bp_submit_bam: %s", ex.what());
+  }
+}
+
+int bp_submit_bam_device(bp_handle* h, const uint8_t* stream, size_t n_bytes, const bp_bam_columns* c,
+                         int64_t first, int64_t n) {
+  if (!h || !c || n < 0 || first < 0 || (n > 0 && !stream)) return fail(h, BP_EINVAL, "bp_submit_bam_device: bad argument");
+  if (n_bytes > 0xffffffffull) return fail(h, BP_EINVAL, "bp_submit_bam_device: more than 4 GiB in one call");
+  if (h->o.stitch) return fail(h, BP_EINVAL, "bp_submit_bam_device: stitch mode needs the read names on the host (use bp_submit_bam)");
+  try {
+    // what bp_submit_bam checks while it reads the fields: every record inside the stream, its
+    // fields inside its block (the scan says so), CIGARs of ops the walk knows
+    std::atomic<int64_t> bad(-1);
+    const size_t N = (size_t)n, chunk = 16384;
+    parallel_for((N + chunk - 1) / chunk, pack_threads(), [&](size_t ci) {
+      for (size_t k = ci * chunk; k < std::min(N, (ci + 1) * chunk); k++) {
+        const size_t i = (size_t)first + k;
+        if ((c->facts[i] & 4) || (uint64_t)c->off[i] + c->bytes[i] > n_bytes) {
+          int64_t cur = bad.load();
+          while ((cur < 0 || (int64_t)k < cur) && !bad.compare_exchange_weak(cur, (int64_t)k)) {}
+          return;
+        }
+      }
+    });
+    if (bad.load() >= 0)
+      return fail(h, BP_EINVAL, "bp_submit_bam_device: record %lld (offset %u) does not fit its block or the bytes given",
+                  (long long)bad.load(), c->off[first + bad.load()]);
+    Src S;
+    S.n = n;
+    S.ref_id = c->ref_id + first;
+    S.pos = c->pos + first;
+    S.mate_ref_id = c->mate_ref_id + first;
+    S.mate_pos = c->mate_pos + first;
+    S.flags = c->flags + first;
+    S.mapq = c->mapq + first;
+    S.n_cigar = c->n_cigar + first;
+    S.l_seq = c->l_seq + first;
+    S.raw_dev = stream;
+    S.off = c->off + first;
+    S.l_name = c->l_name + first;
+    S.rec_bytes = c->bytes + first;
+    S.span = c->span + first;
+    S.cig_facts = c->facts + first;
+    return guarded_submit(h, S, "bp_submit_bam_device");
+  } catch (const std::bad_alloc&) {
+    return fail(h, BP_ENOMEM, "bp_submit_bam_device: out of host memory");
+  } catch (const std::exception& ex) {
+    return fail(h, BP_ENOMEM, "bp_submit_bam_device: %s", ex.what());
   }
 }
 

@@ -109,6 +109,11 @@ class PileupJob:
         self._check(self.lib.bp_submit_bam(self.h, stream.ctypes.data, stream.size,
                                            rec_off.ctypes.data_as(C.POINTER(C.c_uint32)), rec_off.size))
 
+    def submit_bam_device(self, stream_dev, n_bytes, cols, first, n):
+        """records [first, first+n) of a device-side scan (bgzf.Inflater.scan's bp_bam_columns) of
+        the stream at device address stream_dev: nothing of them is read on the host"""
+        self._check(self.lib.bp_submit_bam_device(self.h, stream_dev, n_bytes, C.byref(cols), first, n))
+
     def finish(self):
         self._check(self.lib.bp_finish(self.h))
 

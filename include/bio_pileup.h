@@ -305,6 +305,45 @@ int bp_inflate_stream(bp_inflater* f, void** stream);
 int bp_inflate_timing(const bp_inflater* f, float* inflate_ms, float* crc_ms);
 const char* bp_inflate_last_error(const bp_inflater* f);
 
+/* ---- BAM record scan on the device (second half) -----------------------
+ * What bam.Reader.Read does behind bamprovider's iterator (bamprovider.go:417-435; record layout
+ * per encoding/bam/unmarshal.go:126-224): find the records of an inflated stream and read their
+ * fixed fields - here with the stream resident on the device (bp_inflate_blocks left it there),
+ * so that a record's ~270 bytes never visit the host: 45 bytes of columns per record do.
+ * One column entry per record, in stream order; host memory owned by the caller. */
+typedef struct bp_bam_columns {
+  int64_t cap;      /* entries each array has room for */
+  uint32_t* off;    /* the record's block_size field, as an offset into the stream */
+  int32_t* ref_id;
+  int32_t* pos;
+  int32_t* mate_ref_id;
+  int32_t* mate_pos;
+  uint16_t* flags;
+  uint8_t* mapq;
+  uint8_t* l_name;  /* l_read_name, with the NUL */
+  uint32_t* n_cigar;
+  uint32_t* l_seq;
+  uint32_t* bytes;  /* 4 + block_size */
+  int32_t* span;    /* reference bases the CIGAR consumes (sam.Cigar.Lengths) */
+  uint8_t* facts;   /* bit 0: one M op; bit 1: an op outside MIDNSH; bit 2: the fields do not fit the block */
+} bp_bam_columns;
+/* Scans stream bytes [first, end) on the device (device pointer `stream`, on the inflater's
+ * device; `first` = the start of a record) for whole records: *n of them, columns filled, *exit
+ * = the offset behind the last whole record, *stopped = 1 when a record cut off by `end` (or an
+ * invalid block size) follows there.  The chain of block sizes is walked in parallel stretches
+ * from guessed starts, every guess verified against the walk before it; returns 1 (nothing
+ * filled) when a guess failed and the caller should walk this stream on the host, a negative
+ * BP_E* code on errors (BP_ENOMEM: more records than cols->cap). */
+int bp_bam_scan(bp_inflater* f, const uint8_t* stream, uint64_t first, uint64_t end, int32_t n_ref,
+                bp_bam_columns* cols, int64_t* n, uint64_t* exit, int32_t* stopped);
+/* bp_submit_bam for records [first_record, first_record + n) of such a scan: `stream` is the
+ * DEVICE address of the stream the columns' offsets refer to (on the job's device); nothing of
+ * the records is read on the host.  Only for jobs without stitching (the mate table is keyed by
+ * read names, which are in the stream) and for records whose facts carry neither bit 1 nor bit 2
+ * (the caller hands such records over with bp_submit_bam from a host copy). */
+int bp_submit_bam_device(bp_handle* h, const uint8_t* stream, size_t n_bytes, const bp_bam_columns* cols,
+                         int64_t first_record, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

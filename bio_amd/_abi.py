@@ -70,7 +70,7 @@ EXPORTS = [
     "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
     "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch",
-    "bp_inflate_create", "bp_inflate_destroy", "bp_inflate_blocks", "bp_inflate_device_output", "bp_inflate_stream",
+    "bp_inflate_create", "bp_inflate_destroy", "bp_inflate_blocks", "bp_inflate_blocks_to", "bp_inflate_device_output", "bp_inflate_stream",
     "bp_inflate_timing", "bp_inflate_last_error", "bp_bam_scan", "bp_submit_bam_device",
 ]
 

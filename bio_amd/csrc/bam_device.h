@@ -12,6 +12,7 @@ enum : uint32_t {
   WALK_NO_START = 2,  // no plausible record start behind the cut
   WALK_OVERFLOW = 4,
   WALK_SKIPPED = 8,   // (set by the verifier) the chain passed over this stretch, or stopped before it
+  WALK_REWALKED = 16, // (set by the verifier) the guess was wrong: walked again from the right place
 };
 
 struct WalkStretch {

@@ -40,7 +40,9 @@ __device__ __forceinline__ bool plausible(const uint8_t* base, uint64_t p, uint6
   const int32_t mref = (int32_t)ld32(base, p + 24), mpos = (int32_t)ld32(base, p + 28);
   const uint32_t l_name = w3 & 0xffu, n_cigar = w4 & 0xffffu;
   if (bs < 32 || bs > (1u << 26)) return false;
-  if (ref < -1 || ref >= n_ref || mref < -1 || mref >= n_ref || pos < -1 || mpos < -1 || l_name == 0) return false;
+  // (the mate's reference only has to be an id at all: files with mates on references the header
+  // does not list exist, and a guess that misses a true record costs a serial re-walk)
+  if (ref < -1 || ref >= n_ref || mref < -1 || pos < -1 || mpos < -1 || l_name == 0) return false;
   const uint64_t need = 32 + (uint64_t)l_name + 4 * (uint64_t)n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
   if (need > bs) return false;
   const uint64_t nul = p + 36 + l_name - 1;
@@ -131,14 +133,15 @@ __global__ __launch_bounds__(256) void bam_walk_kernel(const uint8_t* __restrict
 // out[0] = status (0 ok, else 1 + the stretch whose guess was wrong or missing: the caller walks
 // this batch on the host), out[1] = number of records, out[2] = where the walk came out (the first
 // record start not taken), out[3] = 1 when it stopped at a record cut off by the end of the stream.
-__global__ __launch_bounds__(64) void bam_verify_kernel(uint64_t lo, uint64_t end, int32_t n_stretch,
-                                                         WalkStretch* __restrict__ ws, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(64) void bam_verify_kernel(const uint8_t* __restrict__ buf, uint64_t lo, uint64_t end,
+                                                         int32_t n_stretch, WalkStretch* __restrict__ ws,
+                                                         uint32_t* __restrict__ offs, uint32_t* __restrict__ out) {
   constexpr int kTile = 512;
   __shared__ uint32_t t[kTile * 5];
-  __shared__ uint32_t st[4];  // status, total, stopped, done
+  __shared__ uint32_t st[5];  // status, total, stopped, done, stretches walked again
   __shared__ uint64_t at_sh;
   const int lane = (int)threadIdx.x;
-  if (lane == 0) { st[0] = 0; st[1] = 0; st[2] = 0; st[3] = 0; at_sh = lo; }
+  if (lane == 0) { st[0] = 0; st[1] = 0; st[2] = 0; st[3] = 0; st[4] = 0; at_sh = lo; }
   __syncthreads();
   uint32_t* const g = (uint32_t*)ws;
   for (int j0 = 0; j0 < n_stretch; j0 += kTile) {
@@ -154,11 +157,37 @@ __global__ __launch_bounds__(64) void bam_verify_kernel(uint64_t lo, uint64_t en
         if (st[3]) { w[3] |= WALK_SKIPPED; continue; }
         const uint64_t cut1 = min(end, lo + (uint64_t)(j0 + k + 1) * kStretch);
         if (at >= cut1) { w[3] |= WALK_SKIPPED; continue; }  // a long record carried the chain past this stretch
-        if ((w[3] & (WALK_NO_START | WALK_OVERFLOW)) || (uint64_t)w[0] != at) {
+        if (w[3] & WALK_OVERFLOW) {
           st[0] = 1u + (uint32_t)(j0 + k);
           st[3] = 1;
           w[3] |= WALK_SKIPPED;
           continue;
+        }
+        if ((w[3] & WALK_NO_START) || (uint64_t)w[0] != at) {
+          // a guess that was wrong or missing: this stretch is walked again from where the chain
+          // stands, by this one lane (as the host's reader does; rare)
+          uint32_t* const mine = offs + (size_t)(j0 + k) * kMaxPerStretch;
+          uint64_t p = at;
+          uint32_t n = 0, fl = 0;
+          while (p < cut1) {
+            if (end - p < 4) { fl |= WALK_STOPPED; break; }
+            const uint32_t bs = ld32(buf, p);
+            if (bs < 32 || end - p - 4 < bs) { fl |= WALK_STOPPED; break; }
+            if (n >= (uint32_t)kMaxPerStretch) { fl |= WALK_OVERFLOW; break; }
+            mine[n++] = (uint32_t)p;
+            p += 4 + (uint64_t)bs;
+          }
+          if (fl & WALK_OVERFLOW) {
+            st[0] = 1u + (uint32_t)(j0 + k);
+            st[3] = 1;
+            w[3] |= WALK_SKIPPED;
+            continue;
+          }
+          w[0] = (uint32_t)at;
+          w[1] = (uint32_t)p;
+          w[2] = n;
+          w[3] = fl | WALK_REWALKED;
+          st[4]++;
         }
         total += w[2];
         at = w[1];
@@ -176,6 +205,7 @@ __global__ __launch_bounds__(64) void bam_verify_kernel(uint64_t lo, uint64_t en
     out[1] = st[1];
     out[2] = (uint32_t)at_sh;
     out[3] = st[2];
+    out[4] = st[4];
   }
 }
 
@@ -233,7 +263,7 @@ void launch_bam_scan(const uint8_t* buf, uint64_t lo, uint64_t end, int32_t n_re
   if (n_stretch <= 0) return;
   hipLaunchKernelGGL(bam_walk_kernel, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, s, buf, lo, end, n_ref, n_stretch,
                      ws, offs);
-  hipLaunchKernelGGL(bam_verify_kernel, dim3(1), dim3(64), 0, s, lo, end, n_stretch, ws, out4);
+  hipLaunchKernelGGL(bam_verify_kernel, dim3(1), dim3(64), 0, s, buf, lo, end, n_stretch, ws, offs, out4);
 }
 
 void launch_bam_fields(const uint8_t* buf, int32_t n_stretch, const WalkStretch* ws, const uint32_t* offs,

@@ -249,6 +249,130 @@ bool Plausible(const uint8_t* base, size_t p, size_t end, int32_t n_ref) {
 
 }  // namespace
 
+namespace {
+
+// ---- resident mode: the inflated stream stays on the device ------------------------------------
+struct DevStream {  // one batch's stream on the device
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  int dev = -1;
+};
+struct ColStore {  // the scan's columns of one batch, pinned host memory
+  bp_bam_columns c;
+  void* block = nullptr;
+  size_t cap = 0;
+};
+class ResidentPool {
+ public:
+  static ResidentPool& Get() {
+    static ResidentPool* g = new ResidentPool();
+    return *g;
+  }
+  std::shared_ptr<DevStream> TakeDev(int dev, size_t need) {
+    DevStream* d = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t k = 0; k < devs_.size(); k++)
+        if (devs_[k]->dev == dev && devs_[k]->cap >= need) {
+          d = devs_[k];
+          devs_.erase(devs_.begin() + (ptrdiff_t)k);
+          break;
+        }
+    }
+    if (!d) {
+      d = new DevStream();
+      d->dev = dev;
+      d->cap = std::max(need, kDeviceStdCap + 4096);
+      if (hipSetDevice(dev) != hipSuccess || hipMalloc((void**)&d->p, d->cap) != hipSuccess) {
+        (void)hipGetLastError();
+        delete d;
+        return nullptr;
+      }
+    }
+    return std::shared_ptr<DevStream>(d, [this](DevStream* x) {
+      std::unique_lock<std::mutex> lk(mu_);
+      if (devs_.size() < 6 && x->cap <= 2 * kDeviceStdCap) {
+        devs_.push_back(x);
+        return;
+      }
+      lk.unlock();
+      (void)hipSetDevice(x->dev);
+      (void)hipFree(x->p);
+      delete x;
+    });
+  }
+  std::shared_ptr<ColStore> TakeCols(size_t cap) {
+    ColStore* c = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t k = 0; k < cols_.size(); k++)
+        if (cols_[k]->cap >= cap) {
+          c = cols_[k];
+          cols_.erase(cols_.begin() + (ptrdiff_t)k);
+          break;
+        }
+    }
+    if (!c) {
+      c = new ColStore();
+      const size_t N = (std::max<size_t>(cap, 3u << 20) + 63) & ~(size_t)63;
+      void* b = nullptr;
+      if (hipHostMalloc(&b, N * 48, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        b = malloc(N * 48);
+        if (!b) { delete c; return nullptr; }
+        c->block = nullptr;  // (not pinned: freed with free)
+        plain_.push_back(b);
+      } else {
+        c->block = b;
+      }
+      uint8_t* q = (uint8_t*)b;
+      c->cap = N;
+      c->c.cap = (int64_t)N;
+      c->c.off = (uint32_t*)q;          q += 4 * N;
+      c->c.ref_id = (int32_t*)q;        q += 4 * N;
+      c->c.pos = (int32_t*)q;           q += 4 * N;
+      c->c.mate_ref_id = (int32_t*)q;   q += 4 * N;
+      c->c.mate_pos = (int32_t*)q;      q += 4 * N;
+      c->c.n_cigar = (uint32_t*)q;      q += 4 * N;
+      c->c.l_seq = (uint32_t*)q;        q += 4 * N;
+      c->c.bytes = (uint32_t*)q;        q += 4 * N;
+      c->c.span = (int32_t*)q;          q += 4 * N;
+      c->c.flags = (uint16_t*)q;        q += 2 * N;
+      c->c.mapq = q;                    q += N;
+      c->c.l_name = q;                  q += N;
+      c->c.facts = q;
+    }
+    // (column stores are few and of one size: they go back to the pool and stay for the process)
+    return std::shared_ptr<ColStore>(c, [this](ColStore* x) {
+      std::lock_guard<std::mutex> lk(mu_);
+      cols_.push_back(x);
+    });
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<DevStream*> devs_;
+  std::vector<ColStore*> cols_;
+  std::vector<void*> plain_;
+};
+
+struct ResBatch {
+  std::shared_ptr<DevStream> dev;
+  size_t at = 0, size = 0;  // the stream's bytes [at, size); at = the start of a record
+  std::shared_ptr<ColStore> cols;
+  int64_t n = 0;       // whole records found
+  size_t exit = 0;     // the offset behind the last of them
+  // the device scan failed (a guess was wrong): bytes fetched, walked on the host
+  std::shared_ptr<Buf> host;
+  Walk host_walk;
+  bool fields_ok = true, sorted = true, one_ref = true;
+  int32_t r0 = -1, p0 = 0, r1 = -1, p1 = 0;
+  bool eof = false;
+  std::string err;
+};
+
+}  // namespace
+
 struct BamReader::Impl {
   FILE* f = nullptr;
   bool file_eof = false;     // the batch reader met the end of the file
@@ -257,6 +381,13 @@ struct BamReader::Impl {
   std::vector<bp_inflater*> inflaters;
   std::vector<bp_bgzf_block> blk_tab;
   double dev_inflate_ms = 0;
+  // resident mode
+  bool resident = false, res_done = false;
+  int32_t n_ref = 0;
+  std::shared_ptr<ResBatch> res_prev;                // (the read-ahead task's) the batch before, for its tail
+  std::vector<uint8_t> res_init_tail;                // bytes the host-mode reader had not consumed at the switch
+  std::future<std::shared_ptr<ResBatch>> res_next;
+  std::atomic<int64_t> res_fallbacks{0};
   double t_readraw = 0, t_inflate = 0, t_take = 0;  // wall seconds inside ReadRaw / Inflate / buffer allocation (BIO_PILEUP_STATS)
   std::shared_ptr<Buf> cur;  // inflated bytes not yet consumed: cur->p[rd, end)
   size_t rd = 0, end = 0;
@@ -331,7 +462,9 @@ struct BamReader::Impl {
 
   ~Impl() {
     if (next.valid()) next.wait();
+    if (res_next.valid()) res_next.wait();
     if (next_raw.valid()) next_raw.wait();
+    res_prev.reset();
     for (bp_inflater* x : inflaters) bp_inflate_destroy(x);
     if (f) fclose(f);
   }
@@ -438,6 +571,159 @@ struct BamReader::Impl {
     return out;
   }
 
+  // The blocks of R inflated on the device: the compressed bytes as they lie in the file plus one
+  // table entry per block; CRC-32 and ISIZE are checked there.  The batch is cut into parts that
+  // travel and inflate side by side on streams of their own (copies either way overlap the
+  // kernels).  The output goes to host memory (out_host + offset in the batch) or stays on the
+  // device (out_dev + offset).
+  void DeviceInflate(RawBatch& R, int idev, uint8_t* out_host, uint8_t* out_dev, std::string* err) {
+    blk_tab.clear();
+    for (const RawBatch::Blk& b : R.blks)
+      if (b.isize)
+        blk_tab.push_back({(uint32_t)b.off, (uint32_t)b.clen, (uint32_t)(b.out - kHead), (uint32_t)b.isize,
+                           U32(R.raw.data() + b.off + b.clen)});
+    const size_t nb = blk_tab.size();
+    if (nb == 0) return;
+    const size_t parts = std::min<size_t>(kDeviceParts, std::max<size_t>(1, nb / 256));
+    while (inflaters.size() < std::max<size_t>(parts, 1)) {
+      bp_inflater* x = nullptr;
+      if (bp_inflate_create(idev, &x) != BP_OK) { *err = bp_inflate_last_error(nullptr); return; }
+      inflaters.push_back(x);
+    }
+    std::vector<std::string> errs(parts);
+    std::vector<float> ms(parts, 0.f);
+    auto one = [&](size_t k) {
+      const size_t a = nb * k / parts, e = nb * (k + 1) / parts;
+      if (a == e) return;
+      const uint32_t in_lo = blk_tab[a].in_off, in_hi = blk_tab[e - 1].in_off + blk_tab[e - 1].in_len;
+      const uint32_t out_lo = blk_tab[a].out_off, out_hi = blk_tab[e - 1].out_off + blk_tab[e - 1].out_len;
+      for (size_t i = a; i < e; i++) { blk_tab[i].in_off -= in_lo; blk_tab[i].out_off -= out_lo; }
+      int64_t bad = -1;
+      const int rc = out_dev ? bp_inflate_blocks_to(inflaters[k], R.raw.data() + in_lo, in_hi - in_lo, blk_tab.data() + a,
+                                                    (int64_t)(e - a), out_dev + out_lo, out_hi - out_lo, 1, &bad)
+                             : bp_inflate_blocks(inflaters[k], R.raw.data() + in_lo, in_hi - in_lo, blk_tab.data() + a,
+                                                 (int64_t)(e - a), out_host + out_lo, out_hi - out_lo, 1, &bad);
+      if (rc != BP_OK) {
+        const std::string m = bp_inflate_last_error(inflaters[k]);
+        errs[k] = m.compare(0, 5, "bgzf:") == 0 ? "bgzf: corrupt block (inflate or CRC failure)" : m;
+      }
+      float a_ms = 0, c_ms = 0;
+      bp_inflate_timing(inflaters[k], &a_ms, &c_ms);
+      ms[k] = a_ms + c_ms;
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; k++) th.emplace_back(one, k);
+    one(0);
+    for (std::thread& t : th) t.join();
+    float mx = 0;
+    for (size_t k = 0; k < parts; k++) {
+      if (!errs[k].empty() && err->empty()) *err = errs[k];
+      mx = std::max(mx, ms[k]);
+    }
+    dev_inflate_ms += mx;
+  }
+
+  // Resident mode: the next batch read, inflated on the device behind the unconsumed tail of the
+  // batch before it, and scanned there; runs a batch ahead of NextChunk.
+  std::shared_ptr<ResBatch> NextResident() {
+    auto out = std::make_shared<ResBatch>();
+    ResBatch& B = *out;
+    const int idev = inflate_device.load();
+    std::unique_ptr<RawBatch> r = next_raw.valid() ? next_raw.get() : ReadRaw(raw_pos);
+    raw_pos = r->end_pos;
+    if (r->err.empty() && !r->eof) {
+      const uint64_t pos = raw_pos;
+      next_raw = std::async(std::launch::async, [this, pos] { return ReadRaw(pos); });
+    }
+    const auto t_in = std::chrono::steady_clock::now();
+    struct Acc { double* a; std::chrono::steady_clock::time_point t; ~Acc() { *a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{&t_inflate, t_in};
+    B.err = r->err;
+    B.eof = r->eof;
+    auto recycle = [&] {
+      std::lock_guard<std::mutex> lk(spare_mu);
+      if (spare.size() < 3) spare.push_back(std::move(r));
+    };
+    if (!B.err.empty()) return out;
+    const size_t tail = res_prev ? res_prev->size - res_prev->exit : res_init_tail.size();
+    const size_t head = std::max(kHead, (tail + 255) & ~(size_t)255);
+    B.dev = ResidentPool::Get().TakeDev(idev, head + r->out_total + 4096);
+    if (!B.dev) { B.err = "bam: out of device memory"; return out; }
+    B.at = head - tail;
+    B.size = head + r->out_total;
+    if (hipSetDevice(idev) != hipSuccess) { B.err = "hipSetDevice failed"; return out; }
+    if (tail) {
+      const hipError_t e = res_prev ? hipMemcpy(B.dev->p + B.at, res_prev->dev->p + res_prev->exit, tail, hipMemcpyDeviceToDevice)
+                                    : hipMemcpy(B.dev->p + B.at, res_init_tail.data(), tail, hipMemcpyHostToDevice);
+      if (e != hipSuccess) { B.err = std::string("bam: copying a batch's tail: ") + hipGetErrorString(e); return out; }
+    }
+    res_init_tail.clear();
+    res_init_tail.shrink_to_fit();
+    // (blk_tab offsets are relative to kHead in the batch: out_dev is where offset 0 goes)
+    DeviceInflate(*r, idev, nullptr, B.dev->p + head, &B.err);
+    recycle();
+    if (!B.err.empty()) return out;
+    while (inflaters.empty()) {
+      bp_inflater* x = nullptr;
+      if (bp_inflate_create(idev, &x) != BP_OK) { B.err = bp_inflate_last_error(nullptr); return out; }
+      inflaters.push_back(x);
+    }
+    B.cols = ResidentPool::Get().TakeCols((B.size - B.at) / 96 + 4096);
+    if (!B.cols) { B.err = "bam: out of memory"; return out; }
+    uint64_t exit = B.at;
+    int32_t stopped = 0;
+    int rc = B.size > B.at ? bp_bam_scan(inflaters[0], B.dev->p, B.at, B.size, n_ref, &B.cols->c, &B.n, &exit, &stopped) : BP_OK;
+    if (rc == 1 || rc == BP_ENOMEM) {
+      // a guess of the device walk was wrong (or the records are tiny): this batch is walked on the host
+      if (res_fallbacks++ == 0)
+        if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
+          fprintf(stderr, "bam: device scan of a batch gave way to the host's walk (%d): %s\n", rc, bp_inflate_last_error(inflaters[0]));
+      B.cols.reset();
+      B.host = BufPool::Get().Take(B.size - B.at + 64, pinned, B.size - B.at + 64 > kStdCap);
+      if (!B.host) { B.err = "bam: out of memory"; return out; }
+      if (hipMemcpy(B.host->p, B.dev->p + B.at, B.size - B.at, hipMemcpyDeviceToHost) != hipSuccess) {
+        B.err = "bam: copying a batch to the host failed";
+        return out;
+      }
+      WalkFrom(B.host->p - B.at, B.at, B.size, B.size, &B.host_walk);  // (offsets in the stream's coordinates)
+      B.n = (int64_t)B.host_walk.off.size();
+      exit = B.host_walk.exit;
+      B.fields_ok = B.host_walk.fields_ok;
+      B.sorted = B.host_walk.sorted;
+      B.one_ref = B.host_walk.one_ref;
+      B.r0 = B.host_walk.r0; B.p0 = B.host_walk.p0; B.r1 = B.host_walk.r1; B.p1 = B.host_walk.p1;
+    } else if (rc != BP_OK) {
+      B.err = bp_inflate_last_error(inflaters[0]);
+      return out;
+    } else if (B.n > 0) {
+      // what NextChunk's walk surveys, from the columns
+      const bp_bam_columns& c = B.cols->c;
+      const size_t n = (size_t)B.n, chunk = 65536, nch = (n + chunk - 1) / chunk;
+      std::vector<uint8_t> ok(nch, 1), srt(nch, 1), one(nch, 1);
+      const int32_t ref0 = c.ref_id[0];
+      bp_par::parallel_for(nch, HostThreads(), [&](size_t ci) {
+        const size_t a = ci * chunk, e = std::min(n, a + chunk);
+        uint64_t last = a ? OrderKey(c.ref_id[a - 1], c.pos[a - 1]) : 0;
+        for (size_t i = a; i < e; i++) {
+          if (c.facts[i] & 4) ok[ci] = 0;
+          const uint64_t key = OrderKey(c.ref_id[i], c.pos[i]);
+          if (i && key < last) srt[ci] = 0;
+          if (c.ref_id[i] != ref0) one[ci] = 0;
+          last = key;
+        }
+      });
+      for (size_t ci = 0; ci < nch; ci++) {
+        B.fields_ok &= ok[ci] != 0;
+        B.sorted &= srt[ci] != 0;
+        B.one_ref &= one[ci] != 0;
+      }
+      B.r0 = c.ref_id[0]; B.p0 = c.pos[0]; B.r1 = c.ref_id[n - 1]; B.p1 = c.pos[n - 1];
+    }
+    B.exit = (size_t)exit;
+    if (B.eof && B.exit != B.size) B.err = "bam: truncated record";
+    res_prev = B.eof ? nullptr : out;
+    return out;
+  }
+
   std::unique_ptr<Batch> Inflate(std::unique_ptr<RawBatch> in) {
     std::unique_ptr<Batch> out(new Batch);
     Batch& B = *out;
@@ -455,49 +741,7 @@ struct BamReader::Impl {
     t_take += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
     B.size = kHead + R.out_total;
     if (idev >= 0 && !R.blks.empty()) {
-      // On the device: the compressed bytes as they lie in the file plus one table entry per block;
-      // CRC-32 and ISIZE are checked there.  The batch is cut into parts that travel and inflate
-      // side by side on streams of their own (copies either way overlap the kernels).
-      blk_tab.clear();
-      for (const RawBatch::Blk& b : R.blks)
-        if (b.isize)
-          blk_tab.push_back({(uint32_t)b.off, (uint32_t)b.clen, (uint32_t)(b.out - kHead), (uint32_t)b.isize,
-                             U32(R.raw.data() + b.off + b.clen)});
-      const size_t nb = blk_tab.size();
-      const size_t parts = std::min<size_t>(kDeviceParts, std::max<size_t>(1, nb / 256));
-      while (inflaters.size() < parts) {
-        bp_inflater* x = nullptr;
-        if (bp_inflate_create(idev, &x) != BP_OK) { B.err = bp_inflate_last_error(nullptr); return out; }
-        inflaters.push_back(x);
-      }
-      std::vector<std::string> errs(parts);
-      std::vector<float> ms(parts, 0.f);
-      auto one = [&](size_t k) {
-        const size_t a = nb * k / parts, e = nb * (k + 1) / parts;
-        if (a == e) return;
-        const uint32_t in_lo = blk_tab[a].in_off, in_hi = blk_tab[e - 1].in_off + blk_tab[e - 1].in_len;
-        const uint32_t out_lo = blk_tab[a].out_off, out_hi = blk_tab[e - 1].out_off + blk_tab[e - 1].out_len;
-        for (size_t i = a; i < e; i++) { blk_tab[i].in_off -= in_lo; blk_tab[i].out_off -= out_lo; }
-        int64_t bad = -1;
-        if (bp_inflate_blocks(inflaters[k], R.raw.data() + in_lo, in_hi - in_lo, blk_tab.data() + a, (int64_t)(e - a),
-                              B.buf->p + kHead + out_lo, out_hi - out_lo, 1, &bad) != BP_OK) {
-          const std::string m = bp_inflate_last_error(inflaters[k]);
-          errs[k] = m.compare(0, 5, "bgzf:") == 0 ? "bgzf: corrupt block (inflate or CRC failure)" : m;
-        }
-        float a_ms = 0, c_ms = 0;
-        bp_inflate_timing(inflaters[k], &a_ms, &c_ms);
-        ms[k] = a_ms + c_ms;
-      };
-      std::vector<std::thread> th;
-      for (size_t k = 1; k < parts; k++) th.emplace_back(one, k);
-      one(0);
-      for (std::thread& t : th) t.join();
-      float mx = 0;
-      for (size_t k = 0; k < parts; k++) {
-        if (!errs[k].empty() && B.err.empty()) B.err = errs[k];
-        mx = std::max(mx, ms[k]);
-      }
-      dev_inflate_ms += mx;
+      DeviceInflate(R, idev, B.buf->p + kHead, nullptr, &B.err);
     } else if (!R.blks.empty()) {
       uint8_t* const dst = B.buf->p;
       const uint8_t* const raw = R.raw.data();
@@ -616,6 +860,52 @@ BamReader::~BamReader() {}
 void BamReader::SetPinned(bool on) { impl_->pinned = on; }
 void BamReader::SetDeviceInflate(int device) { impl_->inflate_device.store(device); }
 double BamReader::DeviceInflateSeconds() const { return impl_->dev_inflate_ms * 1e-3; }
+int64_t BamReader::ResidentFallbacks() const { return impl_->res_fallbacks.load(); }
+
+std::string BamReader::StartResident(int device) {
+  Impl& m = *impl_;
+  // what the host-mode reader has read ahead is brought in first: its unconsumed bytes become the
+  // tail in front of the first device batch
+  if (m.next.valid()) {
+    std::unique_ptr<Impl::Batch> b = m.next.get();
+    if (!b->err.empty()) return b->err;
+    const size_t tail = m.end - m.rd;
+    m.res_init_tail.assign(m.cur ? m.cur->p + m.rd : nullptr, m.cur ? m.cur->p + m.rd + tail : nullptr);
+    m.res_init_tail.insert(m.res_init_tail.end(), b->buf->p + kHead, b->buf->p + b->size);
+    if (b->eof) m.file_eof = true;
+  } else if (m.cur) {
+    m.res_init_tail.assign(m.cur->p + m.rd, m.cur->p + m.end);
+  }
+  m.cur.reset();
+  m.rd = m.end = 0;
+  m.marks.clear();
+  m.n_ref = (int32_t)header_.ref_lens.size();
+  m.inflate_device.store(device);
+  m.resident = true;
+  return "";
+}
+
+std::string BamReader::FetchHost(Chunk* c) {
+  if (c->data || !c->dev) return "";
+  Impl& m = *impl_;
+  const size_t first = c->off.empty() ? 0 : c->off[0];
+  const size_t n = c->bytes - first;
+  std::shared_ptr<Buf> hb = BufPool::Get().Take(n + 64, m.pinned, n + 64 > kStdCap);
+  if (!hb) return "bam: out of memory";
+  if (hipSetDevice(m.inflate_device.load()) != hipSuccess ||
+      hipMemcpy(hb->p, c->dev + first, n, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return "bam: copying a chunk to the host failed";
+  }
+  struct Both { std::shared_ptr<const void> a; std::shared_ptr<Buf> b; };
+  auto both = std::make_shared<Both>();
+  both->a = c->hold;
+  both->b = hb;
+  c->hold = both;
+  c->data = hb->p - first;  // (record k at data + off[k], as everywhere)
+  return "";
+}
+
 void BamReader::StageSeconds(double* read_raw, double* inflate, double* take) const {
   *read_raw = impl_->t_readraw;
   *inflate = impl_->t_inflate;
@@ -749,6 +1039,41 @@ int BamReader::Next(Raw* r) {
 int BamReader::NextChunk(Chunk* c) {
   Impl& m = *impl_;
   c->off.clear();
+  if (m.resident) {
+    c->dev = nullptr;
+    c->cols = nullptr;
+    c->data = nullptr;
+    for (;;) {
+      if (m.res_done) return 0;
+      const auto w0 = std::chrono::steady_clock::now();
+      std::shared_ptr<ResBatch> b = m.res_next.valid() ? m.res_next.get() : m.NextResident();
+      m.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+      if (!b->err.empty()) {
+        err_ = b->err;
+        m.res_done = true;
+        return -1;
+      }
+      if (b->eof) m.res_done = true;
+      else m.res_next = std::async(std::launch::async, [this] { return impl_->NextResident(); });
+      if (b->n == 0) continue;  // (no whole record yet: a record longer than a batch, or the file's end)
+      c->hold = b;
+      c->dev = b->dev->p;
+      c->bytes = b->exit;
+      c->fields_ok = b->fields_ok;
+      c->sorted = b->sorted;
+      c->one_ref = b->one_ref;
+      c->first_ref = b->r0; c->first_pos = b->p0; c->last_ref = b->r1; c->last_pos = b->p1;
+      c->rewalked = 0;
+      if (b->cols) {
+        c->cols = &b->cols->c;
+        c->off.assign(b->cols->c.off, b->cols->c.off + b->n);
+      } else {
+        c->off = b->host_walk.off;
+        c->data = b->host->p - b->at;
+      }
+      return 1;
+    }
+  }
   int rc = FirstRecord(m, &err_);
   if (rc <= 0) return rc;
   const uint8_t* base = m.cur->p;

@@ -105,6 +105,12 @@ class BamReader {
     bool one_ref = true;    // every record lies on first_ref
     int32_t first_ref = -1, first_pos = 0, last_ref = -1, last_pos = 0;
     int rewalked = 0;       // stretches whose guessed start was wrong (walked again from the right place)
+    // Resident mode (StartResident): the stream stays on the device.  `dev` is its device address
+    // (record k at dev + off[k]), `cols` the device scan's columns (entry k = record k), and `data`
+    // is NULL until FetchHost has brought the bytes over (a batch whose device scan failed comes
+    // with host bytes and without columns).
+    const uint8_t* dev = nullptr;
+    const bp_bam_columns* cols = nullptr;
   };
   int NextChunk(Chunk* c);
   // Inflate into pinned host memory (hipHostMalloc), which bp_submit_bam copies from without
@@ -115,6 +121,14 @@ class BamReader {
   // (pinned) buffers.  Batches are larger then (4,096 blocks instead of 256: the device wants
   // thousands of blocks in flight).  -1: host.  Any time: batches already read ahead stay as they are.
   void SetDeviceInflate(int device);
+  // From here on the inflated stream stays on `device`: blocks are inflated there, records found
+  // and their fixed fields read there (bp_bam_scan), and NextChunk hands out device chunks (see
+  // Chunk::dev).  After Open(); only NextChunk / FetchHost may follow (no Next, no Seek).
+  std::string StartResident(int device);
+  // The bytes of a device chunk copied to host memory (c->data set; c->hold keeps them too).
+  std::string FetchHost(Chunk* c);
+  // Batches whose device scan failed and were walked on the host instead.
+  int64_t ResidentFallbacks() const;
   // Seconds the device spent in the inflate + CRC kernels, and bytes they produced.
   double DeviceInflateSeconds() const;
   // Wall seconds of the read-ahead stages: file reads + header parse, inflate (either kind), and of that

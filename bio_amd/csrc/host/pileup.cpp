@@ -136,6 +136,12 @@ struct Piece {
   const uint8_t* data = nullptr;
   size_t bytes = 0;
   std::vector<uint32_t> off;
+  // a run of records of a DEVICE chunk (BamReader::StartResident): entries [first, first + count) of
+  // the scan's columns; the bytes are on the device and stay there (bp_submit_bam_device)
+  const uint8_t* dev = nullptr;
+  const bp_bam_columns* cols = nullptr;
+  int64_t first = 0, count = 0;
+  bool empty() const { return cols ? count == 0 : off.empty(); }
 };
 
 class Driver {
@@ -211,8 +217,12 @@ class Driver {
   }
 
   std::string SubmitPiece(size_t stream, const Piece& p) {
-    if (p.off.empty()) return "";
+    if (p.empty()) return "";
     Stream& s = streams[stream];
+    if (p.cols) {
+      if (bp_submit_bam_device(s.h, p.dev, p.bytes, p.cols, p.first, p.count) != BP_OK) return HandleErr(s.h);
+      return "";
+    }
     if (bp_submit_bam(s.h, p.data, p.bytes, p.off.data(), (int64_t)p.off.size()) != BP_OK) return HandleErr(s.h);
     return "";
   }
@@ -615,10 +625,6 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     (void)bp_init(opts.Device);
     return bp_last_error(nullptr);
   }
-  // From here on BGZF blocks are inflated on the device (what the reader has read ahead so far,
-  // the header's blocks among it, went through the host threads; BIO_PILEUP_HOST_INFLATE=1 keeps it
-  // that way, as before round 3).
-  if (const char* e = getenv("BIO_PILEUP_HOST_INFLATE"); !(e && *e && *e != '0')) bam.SetDeviceInflate(opts.Device);
   // -devices N | all: N logical devices, mapped round-robin onto the physical ones
   std::vector<int> devices;
   if (opts.Devices != 0) {
@@ -627,6 +633,28 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (opts.Devices < -1 || opts.Devices > 1024) return "Pileup: invalid devices= argument";
     const int n = opts.Devices == -1 ? n_phys : opts.Devices;
     for (int k = 0; k < n; k++) devices.push_back(k % n_phys);
+  }
+  // From here on BGZF blocks are inflated on the device (what the reader has read ahead so far,
+  // the header's blocks among it, went through the host threads; BIO_PILEUP_HOST_INFLATE=1 keeps it
+  // that way, as before round 3).
+  // ... and, where nothing on the host needs the records' bytes (no mate pairing by name, no aux-tag
+  // filters, no region or index seeks, one device), the stream STAYS on the device: records are
+  // found and their fixed fields read there (bp_bam_scan), 45 bytes of columns per record come to
+  // the host instead of the record, and the pack kernel reads the records where the inflate kernel
+  // left them (BIO_PILEUP_HOST_SCAN=1: the bytes come back and the host walks them).
+  bool resident = false;
+  if (const char* e = getenv("BIO_PILEUP_HOST_INFLATE"); !(e && *e && *e != '0')) {
+    const char* hs = getenv("BIO_PILEUP_HOST_SCAN");
+    bool one_device = true;
+    for (int d : devices) one_device &= d == opts.Device;
+    resident = !(hs && *hs && *hs != '0') && !opts.Stitch && opts.MinBagDepth == 0 && !opts.RemoveSq && region_ref < 0 &&
+               !index.loaded() && one_device;
+    if (resident) {
+      std::string err = bam.StartResident(opts.Device);
+      if (!err.empty()) return err;
+    } else {
+      bam.SetDeviceInflate(opts.Device);
+    }
   }
   SetHostThreads(opts.Parallelism);
 
@@ -838,6 +866,7 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
       last_pos = cf.last_pos;
       const int32_t ref = cf.first_ref;
       auto pos_of = [&](size_t i) {
+        if (ck.cols) return ck.cols->pos[i];
         int32_t v;
         memcpy(&v, ck.data + ck.off[i] + 8, 4);
         return v;
@@ -862,15 +891,33 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
         const size_t j = lo;
         if (!open && !(err = open_job()).empty()) break;
         const size_t nf = followers(ref, p0);
-        if (sel.size() < nf + 1) sel.resize(nf + 1);
-        for (size_t k = 0; k <= nf; k++) sel[k].assign(ck.off.begin() + (ptrdiff_t)i, ck.off.begin() + (ptrdiff_t)j);
         st.records_kept += (int64_t)(j - i);
-        err = flush_sel();
+        if (ck.cols) {
+          // a device chunk: the run is a range of the scan's columns, nothing is copied
+          for (size_t k = 0; k <= nf && err.empty(); k++) {
+            Piece p;
+            p.hold = ck.hold;
+            p.dev = ck.dev;
+            p.cols = ck.cols;
+            p.bytes = ck.bytes;
+            p.first = (int64_t)i;
+            p.count = (int64_t)(j - i);
+            while (pend.size() <= k) pend.emplace_back();
+            if (k == 0) err = push_piece(std::move(p));  // (the front job is open)
+            else pend[k].push_back(std::move(p));
+          }
+        } else {
+          if (sel.size() < nf + 1) sel.resize(nf + 1);
+          for (size_t k = 0; k <= nf; k++) sel[k].assign(ck.off.begin() + (ptrdiff_t)i, ck.off.begin() + (ptrdiff_t)j);
+          err = flush_sel();
+        }
         i = j;
       }
       continue;
     }
-    // ---- record by record
+    // ---- record by record (a device chunk's bytes come to the host for it)
+    if (!ck.data && !(err = bam.FetchHost(&ck)).empty()) break;
+    ck.cols = nullptr;
     for (size_t i = 0; i < n && err.empty(); i++) {
       const uint8_t* rec = ck.data + ck.off[i];
       st.records_read++;
@@ -976,10 +1023,10 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
             "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
-            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) total_s=%.3f\n",
+            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) resident=%d (host walks %lld) total_s=%.3f\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
             index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, st.close_wait_s,
-            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, st.total_s);
+            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, resident ? 1 : 0, (long long)bam.ResidentFallbacks(), st.total_s);
   return "";
 }
 

@@ -52,6 +52,7 @@ struct bp_inflater {
   uint32_t* h_status = nullptr; // pinned
   size_t h_status_cap = 0;
   float inflate_ms = 0, crc_ms = 0;
+  int64_t rewalked = 0;  // stretches of all scans whose guess was wrong
   std::string err;
 };
 
@@ -164,8 +165,24 @@ void bp_inflate_destroy(bp_inflater* f) {
   delete f;
 }
 
+static int inflate_impl(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
+                        int64_t n_blocks, uint8_t* out_host, uint8_t* out_device, size_t out_bytes, int32_t check_crc,
+                        int64_t* bad_block);
+
 int bp_inflate_blocks(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
                       int64_t n_blocks, uint8_t* out_host, size_t out_bytes, int32_t check_crc, int64_t* bad_block) {
+  return inflate_impl(f, comp, comp_bytes, blocks, n_blocks, out_host, nullptr, out_bytes, check_crc, bad_block);
+}
+
+int bp_inflate_blocks_to(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
+                         int64_t n_blocks, uint8_t* out_device, size_t out_bytes, int32_t check_crc, int64_t* bad_block) {
+  if (!out_device && out_bytes) return ifail(f, BP_EINVAL, "bp_inflate_blocks_to: null output");
+  return inflate_impl(f, comp, comp_bytes, blocks, n_blocks, nullptr, out_device, out_bytes, check_crc, bad_block);
+}
+
+static int inflate_impl(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
+                        int64_t n_blocks, uint8_t* out_host, uint8_t* out_device, size_t out_bytes, int32_t check_crc,
+                        int64_t* bad_block) {
   if (bad_block) *bad_block = -1;
   if (!f || n_blocks < 0 || (n_blocks > 0 && (!comp || !blocks)))
     return ifail(f, BP_EINVAL, "bp_inflate_blocks: bad argument");
@@ -187,7 +204,9 @@ int bp_inflate_blocks(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, co
   // (the bit reader loads whole 256-byte windows up to two ahead: 1 KiB of slack behind the data)
   if (int rc = grow(f, f->comp, comp_bytes + 1024)) return rc;
   if (int rc = grow(f, f->blks, (size_t)n_blocks * sizeof(InflateBlock))) return rc;
-  if (int rc = grow(f, f->out, out_bytes + 256)) return rc;
+  if (!out_device)
+    if (int rc = grow(f, f->out, out_bytes + 256)) return rc;
+  uint8_t* const dout = out_device ? out_device : (uint8_t*)f->out.p;
   if (int rc = grow(f, f->status, (size_t)n_blocks * 4)) return rc;
   if (f->h_status_cap < (size_t)n_blocks) {
     if (f->h_status) INF_TRY(f, hipHostFree(f->h_status));
@@ -200,16 +219,16 @@ int bp_inflate_blocks(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, co
   INF_TRY(f, hipMemcpyAsync(f->comp.p, comp, comp_bytes, hipMemcpyHostToDevice, f->stream));
   INF_TRY(f, hipMemcpyAsync(f->blks.p, blocks, (size_t)n_blocks * sizeof(InflateBlock), hipMemcpyHostToDevice, f->stream));
   INF_TRY(f, hipEventRecord(f->ev[0], f->stream));
-  launch_inflate((const uint8_t*)f->comp.p, (const InflateBlock*)f->blks.p, (int)n_blocks, (uint8_t*)f->out.p,
+  launch_inflate((const uint8_t*)f->comp.p, (const InflateBlock*)f->blks.p, (int)n_blocks, dout,
                  (uint32_t*)f->status.p, f->stream);
   INF_TRY(f, hipEventRecord(f->ev[1], f->stream));
   if (check_crc)
-    launch_bgzf_crc((const uint8_t*)f->out.p, (const InflateBlock*)f->blks.p, (int)n_blocks, f->tables,
+    launch_bgzf_crc(dout, (const InflateBlock*)f->blks.p, (int)n_blocks, f->tables,
                     (uint32_t*)f->status.p, f->stream);
   INF_TRY(f, hipEventRecord(f->ev[2], f->stream));
   INF_TRY(f, hipGetLastError());
   INF_TRY(f, hipMemcpyAsync(f->h_status, f->status.p, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, f->stream));
-  if (out_host && out_bytes) INF_TRY(f, hipMemcpyAsync(out_host, f->out.p, out_bytes, hipMemcpyDeviceToHost, f->stream));
+  if (out_host && out_bytes) INF_TRY(f, hipMemcpyAsync(out_host, dout, out_bytes, hipMemcpyDeviceToHost, f->stream));
   INF_TRY(f, hipStreamSynchronize(f->stream));
   (void)hipEventElapsedTime(&f->inflate_ms, f->ev[0], f->ev[1]);
   (void)hipEventElapsedTime(&f->crc_ms, f->ev[1], f->ev[2]);
@@ -239,7 +258,7 @@ int bp_bam_scan(bp_inflater* f, const uint8_t* stream, uint64_t first, uint64_t 
   uint32_t* d_out = (uint32_t*)f->status.p;
   launch_bam_scan(stream, first, end, n_ref, ns, (WalkStretch*)f->walk.p, (uint32_t*)f->offs.p, d_out, f->stream);
   INF_TRY(f, hipGetLastError());
-  INF_TRY(f, hipMemcpyAsync(f->h_scan, d_out, 16, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipMemcpyAsync(f->h_scan, d_out, 20, hipMemcpyDeviceToHost, f->stream));
   INF_TRY(f, hipStreamSynchronize(f->stream));
   if (f->h_scan[0] != 0) {  // a guess failed: the host walks this stream
     const uint32_t j = f->h_scan[0] - 1;
@@ -255,6 +274,7 @@ int bp_bam_scan(bp_inflater* f, const uint8_t* stream, uint64_t first, uint64_t 
   *n_out = n;
   *exit_out = f->h_scan[2];
   *stopped_out = (int32_t)f->h_scan[3];
+  f->rewalked += f->h_scan[4];
   if (n == 0) return BP_OK;
   // device columns: one allocation, 48 bytes a record
   const size_t N = ((size_t)n + 63) & ~(size_t)63;

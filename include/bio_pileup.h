@@ -297,6 +297,11 @@ void bp_inflate_destroy(bp_inflater* f);
  * for a block table that does not fit the bytes given. */
 int bp_inflate_blocks(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
                       int64_t n_blocks, uint8_t* out_host, size_t out_bytes, int32_t check_crc, int64_t* bad_block);
+/* The same, with the output written to device memory of the caller's (out_device, out_bytes of it,
+ * on the inflater's device) and not copied anywhere: for callers that keep the inflated stream
+ * on the device (bp_bam_scan, bp_submit_bam_device). */
+int bp_inflate_blocks_to(bp_inflater* f, const uint8_t* comp, size_t comp_bytes, const bp_bgzf_block* blocks,
+                         int64_t n_blocks, uint8_t* out_device, size_t out_bytes, int32_t check_crc, int64_t* bad_block);
 /* The last call's output on the device (out_bytes of it), valid until the next call or destroy;
  * bp_inflate_stream: the stream it was written on (for callers that order other work behind it). */
 const uint8_t* bp_inflate_device_output(const bp_inflater* f);

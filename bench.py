@@ -195,14 +195,20 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
             fld = ln.split(b"\t")
             if int(fld[1]) != i + 1 or [int(x) for x in fld[3:11]] != dv[i][1:9].tolist() or fld[2] != bytes(seq[i:i + 1]):
                 raise SystemExit(f"e2e: line {i + 2} of the output differs from the device rows")
-        m = re.search(r"read_s=([0-9.]+).*waiting for inflated blocks ([0-9.]+).*device_inflate_s=([0-9.]+).*total_s=([0-9.]+)", r.stderr)
+        m = re.search(r"read_s=([0-9.]+).*waiting for inflated blocks ([0-9.]+).*device_inflate_s=([0-9.]+).*"
+                      r"resident=(\d) \(host walks (\d+)\).*total_s=([0-9.]+)", r.stderr)
+        resident = bool(m and m.group(4) == "1")
+        how = ("the inflated stream stays on the device: records found and their fields read there (bp_bam_scan), "
+               "packed in place (bp_submit_bam_device)" if resident else
+               "records found on the host, packed on the device (bp_submit_bam)")
         blk = {"value": round(B / wall / 1e9, 3), "unit": "Gbase/s", "wall_s": round(wall, 2),
                "what": f"bio-pileup {' '.join(x for x in flags if not x.startswith('/'))}: BAM ({os.path.getsize(bam) / 1e9:.2f} GB, "
                        f"BGZF level 1, {rb.n} records) + FASTA + BED -> basestrand.tsv ({out_bytes / 1e9:.2f} GB) on local disk, "
-                       f"process start to files closed; BGZF inflated on the device (bp_inflate_blocks), records found on "
-                       f"the host, packed on the device (bp_submit_bam), text rendered on the device",
+                       f"process start to files closed; BGZF inflated on the device (bp_inflate_blocks), {how}, "
+                       f"text rendered on the device",
                "driver_stats": {"read_s": float(m.group(1)), "waiting_for_inflate_s": float(m.group(2)),
-                                "device_inflate_kernels_s": float(m.group(3)), "total_s": float(m.group(4))} if m else None,
+                                "device_inflate_kernels_s": float(m.group(3)), "resident": resident,
+                                "host_walks": int(m.group(5)), "total_s": float(m.group(6))} if m else None,
                "inputs_made_in_s": round(make_s, 1)}
         for pth in (outp, bam):
             os.remove(pth)

@@ -284,6 +284,38 @@ def test_job_cuts_with_halo_change_nothing(tmp_path, stitch, monkeypatch):
         assert c.read("sub.basestrand.tsv") == want, span
 
 
+def test_reader_modes_write_the_same_files(tmp_path, monkeypatch, capfd):
+    """The three ways the BAM reaches the pack kernel - inflated stream resident on the device with
+    records found there (the default without stitching), device inflate with the host's record walk
+    (BIO_PILEUP_HOST_SCAN=1), zlib on host threads (BIO_PILEUP_HOST_INFLATE=1) - write the same
+    bytes, also with one-block batches (records straddle every batch edge) and small jobs; the
+    stats line says which one ran."""
+    c = Case(tmp_path, seed=77)
+    o = Opts(BedPath=c.bed_path, MinBaseQual=20, MaxReadLen=150, MaxReadSpan=300)
+    want = render_basestrand(c.oracle(min_base_qual=20, max_read_len=150, max_read_span=300),
+                             c.ref_names, c.ref_ascii)
+    monkeypatch.setenv("BIO_PILEUP_STATS", "1")
+    for blocks, span in ((0, 0), (1, 0), (2, 700)):
+        if blocks:
+            monkeypatch.setenv("BIO_PILEUP_BATCH_BLOCKS", str(blocks))
+        if span:
+            monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", str(span))
+        for env, resident in ((None, 1), ("BIO_PILEUP_HOST_SCAN", 0), ("BIO_PILEUP_HOST_INFLATE", 0)):
+            if env:
+                monkeypatch.setenv(env, "1")
+            capfd.readouterr()
+            host.pileup(c.bam, c.fa, "basestrand-tsv", str(tmp_path / "m"), o)
+            err = capfd.readouterr().err
+            if env:
+                monkeypatch.delenv(env)
+            assert c.read("m.basestrand.tsv") == want, (blocks, span, env)
+            assert "resident=%d" % resident in err, err
+            if resident:
+                assert "(host walks 0)" in err, err
+            if env == "BIO_PILEUP_HOST_INFLATE":
+                assert "device_inflate_s=0.000" in err, err
+
+
 @pytest.mark.parametrize("fmt_cols", [("basestrand-tsv", ""), ("tsv", "dpref,quals,strands")])
 def test_jobs_spread_over_devices_change_nothing(tmp_path, monkeypatch, fmt_cols):
     """-devices N: job k runs on logical device k mod N (mapped round-robin onto the GPUs present:

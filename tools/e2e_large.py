@@ -46,14 +46,20 @@ del rb
 exe = os.path.join(ROOT, "bio_amd", "bio-pileup")
 import hashlib
 rc_all, sums = 0, {}
-# E2E_MODES: "device" (BGZF inflate on the GPU, the default of the driver) and/or "host"
+# E2E_MODES: "device" (the driver's default: BGZF inflate and record scan on the GPU), "scan", "host", "rocprof"
 for mode in os.environ.get("E2E_MODES", "device,host").split(","):
     env = dict(os.environ, BIO_PILEUP_STATS="1", BP_PROFILE="1")
     if mode == "host":
         env["BIO_PILEUP_HOST_INFLATE"] = "1"
+    if mode == "scan":  # device inflate, records found by the host's walk
+        env["BIO_PILEUP_HOST_SCAN"] = "1"
+    cmd = [exe, "-bed", bed, "-format", fmt, *extra, "-out", os.path.join(d, "o"), bam, fa]
+    if mode == "rocprof":  # the default mode under rocprofv3's kernel trace (E2E_ROCPROF_DIR holds the csv files)
+        env.pop("BP_PROFILE")
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d",
+               os.environ.get("E2E_ROCPROF_DIR", os.path.join(ROOT, "gpurun_out", "e2e_rocprof")), "--"] + cmd
     t0 = time.time()
-    r = subprocess.run([exe, "-bed", bed, "-format", fmt, *extra, "-out", os.path.join(d, "o"), bam, fa],
-                       capture_output=True, text=True, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     wall = time.time() - t0
     print(r.stderr.strip()[-2600:], flush=True)
     outs = sorted(p for p in os.listdir(d) if p.startswith("o."))

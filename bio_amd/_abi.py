@@ -61,6 +61,7 @@ class bp_timing(C.Structure):
         ("per_read_scan_ms", C.c_float),
         ("submit_scan_ms", C.c_float),
         ("submit_pack_ms", C.c_float),
+        ("stitch_resolve_ms", C.c_float),
     ]
 
 

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(kPackBlock) void pack_records(const uint8_t* __rest
   const uint32_t ncp = (n_cigar + 1) & ~1u;
   const uint32_t U = (l + 7) >> 3;  // blob_units()
   const uint32_t sb = (l + 1) >> 1;
-  const uint32_t qp_dw = qpass ? (U + 3) >> 2 : 0u;       // pass bits, one per base, to a whole dword
+  // pass bits, one per base, to a whole dword; qpass == 2 (stitch): each followed by a dword of
+  // drop bits, zero here
+  const uint32_t qp_dw = qpass ? (uint32_t)qpass * ((U + 3) >> 2) : 0u;
   const uint32_t base_dw = (ncp + U + qp_dw + 1) & ~1u;   // base_part_bytes() / 4, to whole 8-byte units
   uint32_t* const d = (uint32_t*)(blob + (size_t)it.blob * 8);
   for (uint32_t w = lane; w < base_dw; w += 64) {
@@ -77,9 +79,9 @@ __global__ __launch_bounds__(kPackBlock) void pack_records(const uint8_t* __rest
       const uint32_t b0 = 4 * (w - ncp);
       v = b0 < sb ? ld_upto4(seq + b0, sb - b0) : 0u;
       v = ((v & 0x0f0f0f0fu) << 4) | ((v >> 4) & 0x0f0f0f0fu);  // first base of a byte to the low nibble
-    } else if (w >= ncp + U && w - (ncp + U) < qp_dw) {
+    } else if (w >= ncp + U && w - (ncp + U) < qp_dw && (qpass != 2 || ((w - (ncp + U)) & 1u) == 0)) {
       // bit b of the dword: base 32t + b passes the quality rule (clipQuals, then addBase's test)
-      const uint32_t b0 = 32 * (w - (ncp + U));
+      const uint32_t b0 = 32 * ((w - (ncp + U)) >> (qpass == 2 ? 1 : 0));
       for (uint32_t b = 0; b < 32 && b0 + b < l; b++) {
         const uint32_t i = b0 + b;
         uint32_t q = qual[i];

@@ -33,6 +33,7 @@
 namespace bp {
 void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s);
 void launch_pileup(const KernelParams& P, hipStream_t s);
+void launch_stitch_resolve(const KernelParams& P, hipStream_t s);
 void launch_column_sums(const uint32_t* rows, int64_t n_rows, unsigned long long* sums, hipStream_t s);
 void launch_rows_add(uint32_t* rows, const uint32_t* src, int64_t n_u32, hipStream_t s);
 int window_size();
@@ -320,7 +321,7 @@ struct bp_handle {
   std::vector<std::string> ref_name;
   std::vector<std::vector<int32_t>> bed;  // per reference endpoint arrays
   bool frozen = false;                    // BED fixed, windows built
-  bool qpass = false;                     // payloads carry one pass bit per base (pileup_device.h): every job but those in which every base passes
+  int qpass = 0;                          // dwords of per-base bits per 32 bases in the payloads (pileup_device.h): 0 when every base passes, 1 pass bits, 2 (stitch) pass + drop bits
   bool finished = false;
   std::string err;
   // A bp_submit that failed part-way has already moved the order key, the per-reference record
@@ -366,6 +367,7 @@ struct bp_handle {
   std::vector<uint64_t> scan_hash;
   double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // BP_PROFILE=1: extract, layout, scan-par, scan-serial, items, ensure, copy wait, total
   double scan_s = 0, pack_s = 0;                      // host time in bp_submit so far: serial scan (order, errors, pairing) / parallel passes
+  double resolve_ms = 0;                              // stitch: stitch_resolve_kernel, all its runs
   uint8_t qthr[96];
 
   // device
@@ -1035,7 +1037,7 @@ int bp_create(const bp_opts* opts, int32_t n_ref, const int32_t* ref_len, const 
   if (int rc = bp_init(opts->device)) return rc;
   bp_handle* h = new bp_handle();
   h->o = *opts;
-  h->qpass = opts->stitch || opts->min_base_qual > 0;
+  h->qpass = opts->stitch ? 2 : opts->min_base_qual > 0 ? 1 : 0;
   h->device = opts->device;
   h->ref_len.assign(ref_len, ref_len + n_ref);
   h->ref_name.resize((size_t)n_ref);
@@ -1071,7 +1073,7 @@ int bp_reserve(bp_handle* h, int64_t n_records, int64_t payload_bytes) {
   // (and by one pass bit per base where the job has them: l_seq <= 2/3 of the payload, a dword of
   // padding per record)
   size_t blob = (size_t)payload_bytes + (size_t)n_records * 24 + 4096;
-  if (h->qpass) blob += (size_t)payload_bytes / 8 + (size_t)n_records * 8;
+  if (h->qpass) blob += (size_t)h->qpass * ((size_t)payload_bytes / 8 + (size_t)n_records * 8);
   if (int rc = ensure(h, h->d_cores, (size_t)n_records * sizeof(ReadCore) + 256, (size_t)h->n_reads * sizeof(ReadCore))) return rc;
   if (int rc = ensure(h, h->d_blob, blob, (size_t)h->blob_used * 8)) return rc;
   return BP_OK;
@@ -1295,7 +1297,7 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       h->prof[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack).count();
       HIP_TRY(h, hipMemcpyAsync(h->d_pack.p, st->items, ns * sizeof(PackItem), hipMemcpyHostToDevice, h->stream));
       launch_pack(S.raw_dev ? S.raw_dev + raw_first : (const uint8_t*)h->d_raw.p, (const PackItem*)h->d_pack.p, (int64_t)ns, (ReadCore*)h->d_cores.p + h->n_reads,
-                  (uint8_t*)h->d_blob.p, h->qpass ? 1 : 0, h->o.min_base_qual, h->o.clip, h->stream);
+                  (uint8_t*)h->d_blob.p, h->qpass, h->o.min_base_qual, h->o.clip, h->stream);
       HIP_TRY(h, hipGetLastError());
     } else {
       const bp_record_batch* b = S.b;
@@ -1361,7 +1363,8 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
                 bits = minq <= 2 ? (bits | cm) : (bits & ~cm);
               }
               if (8 * j + 8 > l) bits &= (1u << (l - 8 * j)) - 1u;  // pad bits 0, as pack_records leaves them
-              m[j] = (uint8_t)bits;
+              // (stitch: a dword of drop bits, zero here, follows every dword of pass bits)
+              m[h->qpass == 2 ? (size_t)(j >> 2) * 8 + (j & 3u) : (size_t)j] = (uint8_t)bits;
             }
           }
           local += 32 + 4 * (int64_t)n_cigar + ((int64_t)b->l_seq[i] + 1) / 2 + b->l_seq[i];
@@ -1583,7 +1586,7 @@ static void fill_params(bp_handle* h, KernelParams& P) {
   P.mapq = h->o.mapq;
   P.min_base_qual = h->o.min_base_qual;
   P.stitch = h->o.stitch;
-  P.qpass = h->qpass ? 1 : 0;
+  P.qpass = h->qpass;
   P.ignore_strand = h->o.ignore_strand;
   P.strand_req = h->o.strand_req;
 }
@@ -1623,12 +1626,16 @@ int bp_compute(bp_handle* h) {
   if (h->poison_code) return fail(h, h->poison_code, "%s", h->poison_msg.c_str());
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = freeze_bed(h)) return rc;
+  bool need_resolve = false;
   if (h->o.stitch) {
     const size_t bytes = (size_t)h->n_reads * sizeof(MateEntry);
     if (int rc = ensure(h, h->d_mate, std::max<size_t>(bytes, 256), 0)) return rc;
     // (only after a submit: pairing can reach back to records of earlier submits, so the whole
     // table goes again then; a compute that follows a compute moves nothing)
-    if (bytes && h->mate_dirty) HIP_TRY(h, hipMemcpyAsync(h->d_mate.p, h->mate.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    if (bytes && h->mate_dirty) {
+      HIP_TRY(h, hipMemcpyAsync(h->d_mate.p, h->mate.data(), bytes, hipMemcpyHostToDevice, h->stream));
+      need_resolve = true;
+    }
     h->mate_dirty = false;
   }
   if (int rc = ensure(h, h->d_err, 256, 0)) return rc;
@@ -1662,6 +1669,18 @@ int bp_compute(bp_handle* h) {
   HIP_TRY(h, hipMemsetAsync(h->d_dbg.p, 0, h->windows.size() * 8 * (8 * 8 + 8 * 4), h->stream));
   P.dbg = (unsigned long long*)h->d_dbg.p;
 #endif
+  if (need_resolve) {
+    // the pair rule, once for the pairs the table has gained (each pair is worked once: the
+    // kernel marks the reads it has done); the counting kernels then find its outcome in the payloads
+    HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    launch_stitch_resolve(P, h->stream);
+    HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventSynchronize(h->ev[1]));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    h->resolve_ms += ms;
+  }
   DeviceError got{};
   if (int rc = run_kernels(h, P, &got)) return rc;
   h->resident = h->finished;
@@ -2049,6 +2068,7 @@ int bp_get_timing(const bp_handle* h, bp_timing* out) {
   *out = h->timing;
   out->submit_scan_ms = (float)(h->scan_s * 1e3);
   out->submit_pack_ms = (float)(h->pack_s * 1e3);
+  out->stitch_resolve_ms = (float)h->resolve_ms;
   return BP_OK;
 }
 

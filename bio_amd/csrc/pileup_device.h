@@ -31,7 +31,11 @@ enum : uint8_t {
   // what the record-level tests of processShard come to under the job's options, worked out
   // once by the packer (the per-read gather reads these; the pileup kernel does the tests):
   AUX_KEEP = 4,       // passes flag-exclude, mapq, empty CIGAR and the strand rule (pileup.go:691, :717-729)
-  AUX_STRAND_SHIFT = 4  // bits 4-5: pileup.GetStrand (0 none, 1 fwd, 2 rev)
+  AUX_STRAND_SHIFT = 4,  // bits 4-5: pileup.GetStrand (0 none, 1 fwd, 2 rev)
+  // stitch: set by stitch_resolve_kernel on the read of a pair that was stored first - the pair is
+  // counted on the strand of the read that found its mate (pileup.go:799-802), bit 7 = that is "-"
+  AUX_PAIR_FIRST = 64,
+  AUX_PAIR_REV = 128
 };
 
 // Payload of a record, two 8-byte aligned parts (U = ceil(l_seq/8)):
@@ -45,6 +49,16 @@ enum : uint8_t {
 //                                  per base what the counting kernel would work out from the qual:
 //                                  that kernel then loads 4 bytes per unit of 32 bases instead of
 //                                  36, and the clip variant is the same kernel.  Padded to a dword.
+//                                  Stitched jobs (qbits = 2): every dword of pass bits is followed by
+//                                  a dword of DROP bits for the same 32 bases, zero from the packer.
+//                                  stitch_resolve_kernel (once per job, before the first compute)
+//                                  decides the positions both reads of a pair cover (addReadPair,
+//                                  pileup.go:406-446) and leaves the outcome in the payloads: the
+//                                  read stored first gets its drop bits set there (not counted), the
+//                                  read that found its mate gets base X where the reads disagree and
+//                                  its pass bit = the qualSumTable rule where they agree.  Pass and
+//                                  drop both set: a quality >= 96 at an agreeing position, where the
+//                                  reference panics; the counting kernel reports it when it gets there.
 //               pad to 8 bytes
 //   qual part   uint8  qual[8*U]   pad bytes 0
 // Records are packed in groups of up to kGroupRecs: the base parts of a group back to back,
@@ -56,14 +70,15 @@ constexpr uint64_t kGroupBytes = 400 << 10;  // keeps qdelta (16 bits of 8-byte 
 inline uint32_t blob_units(uint32_t l_seq) { return (l_seq + 7) >> 3; }
 // qpass: the base part ends with one bit per base, "this base passes the job's quality rule"
 // (bit k of byte j = base 8j + k; U bytes padded to a dword), see KernelParams.qpass.
-inline uint64_t base_part_bytes(uint32_t n_cigar, uint32_t l_seq, bool qpass = false) {
+// qbits: dwords of per-base bits per 32 bases (0 none, 1 pass bits, 2 pass + drop bits)
+inline uint64_t base_part_bytes(uint32_t n_cigar, uint32_t l_seq, int qbits = 0) {
   const uint64_t U = blob_units(l_seq);
-  uint64_t b = (uint64_t)((n_cigar + 1) & ~1u) * 4 + 4 * U + (qpass ? 4 * ((U + 3) >> 2) : 0);
+  uint64_t b = (uint64_t)((n_cigar + 1) & ~1u) * 4 + 4 * U + (uint64_t)qbits * 4 * ((U + 3) >> 2);
   return (b + 7) & ~(uint64_t)7;
 }
 inline uint64_t qual_part_bytes(uint32_t l_seq) { return 8 * (uint64_t)blob_units(l_seq); }
-inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq, bool qpass = false) {
-  return base_part_bytes(n_cigar, l_seq, qpass) + qual_part_bytes(l_seq);
+inline uint64_t blob_bytes(uint32_t n_cigar, uint32_t l_seq, int qbits = 0) {
+  return base_part_bytes(n_cigar, l_seq, qbits) + qual_part_bytes(l_seq);
 }
 
 // A genomic window: at most W consecutive positions of one reference, covering BED
@@ -80,7 +95,7 @@ struct Window {
 static_assert(sizeof(Window) == 40, "Window must be 40 bytes");
 
 // Mate table entry for stitch mode, one per record, all zero = processed alone.  It carries what
-// the kernel's phase 1 needs of the record's mate (firstread.go:176-204 decides the pairs, on the
+// stitch_resolve_kernel needs of the record's mate (firstread.go:176-204 decides the pairs, on the
 // host), so that no second record has to be fetched there:
 //   x     0..16 mate start - own start (17 bits two's complement; a pair lies within one span)
 //         17    this record found its mate in the table (readPair[0], firstread.go:187)
@@ -106,7 +121,7 @@ enum { ERR_NONE = 0, ERR_QUAL_RANGE = 1, ERR_ITEM_OVERFLOW = 2 };
 struct KernelParams {
   const ReadCore* cores;
   const uint8_t* blob;
-  const MateEntry* mate;      // NULL unless stitch
+  const MateEntry* mate;      // NULL unless stitch (read by stitch_resolve_kernel only)
   const Window* windows;
   const int32_t* win_r0;      // per window: first record that may overlap it
   const int32_t* win_r1;      // per window: one past the last record starting before g1
@@ -132,7 +147,7 @@ struct KernelParams {
   int32_t max_span;           // largest (clamped) span among submitted records
   // options (bp_opts)
   int32_t clip, flag_exclude, mapq, min_base_qual, stitch, ignore_strand, strand_req;
-  int32_t qpass;              // the payloads carry pass bits (see the payload layout)
+  int32_t qpass;              // dwords of per-base bits per 32 bases in the payloads: 0, 1 pass bits, 2 pass + drop bits (see the payload layout)
   int32_t wins_per_block;     // consecutive windows a workgroup of pileup_kernel takes (set by launch_pileup)
 };
 

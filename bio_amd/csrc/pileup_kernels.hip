@@ -170,16 +170,9 @@ constexpr int kUnitPos = 32;               // window positions per unit
 constexpr int kSub = kW / kUnitPos + 1;    // padded sub-row: 32 residues x kSub
 constexpr int kStride = kUnitPos * kSub;   // dwords per counter plane (multiple of 32)
 constexpr int kSegCap = BP_SEGCAP;   // M-segments per round
-// ... 400 in the variants that keep per-segment extras (stitch, clip): with them a workgroup's
-// LDS has to stay under half a CU's 160 KB
-#ifndef BP_SEGCAP_EXTRA
-#define BP_SEGCAP_EXTRA 400
-#endif
-constexpr int kSegCapExtra = BP_SEGCAP_EXTRA;
-template <bool EXTRA> constexpr int seg_cap() { return EXTRA ? kSegCapExtra : kSegCap; }
 constexpr int kUnitCap = BP_UNITCAP; // units (32 window positions of one segment) per round
 constexpr int kDepth = BP_DEPTH;     // units in flight per lane (software pipeline depth)
-constexpr int kDepthQ = BP_DEPTHQ;   // ... when the quals are loaded too
+constexpr int kDepthQ = BP_DEPTHQ;   // ... in the stitched variants (16 bytes of bits per unit)
 constexpr int kWinPerBlockMax = BP_WINS; // consecutive windows per workgroup (KernelParams::wins_per_block)
 
 // LDS histogram: 12 counter planes (A+ A- C+ C- G+ G- T+ T- X+ X- lowq+ lowq-), each plane
@@ -192,29 +185,10 @@ constexpr int kWinPerBlockMax = BP_WINS; // consecutive windows per workgroup (K
 //    the unit slots are handed to lanes in an order that keeps the 8 groups of 8 lanes of a
 //    wave an eighth of the window apart (see issue_unit).
 //  * flush: 32 consecutive positions of one plane sit at banks r + j: all distinct.
-// Per-segment fields only the stitched and clipped paths read back.
-struct SegExtra {
-  int32_t s_ref[kSegCapExtra];       // segment start relative to the window start (may be < 0)
-  uint32_t s_lenq0[kSegCapExtra];    // length | read offset << 16
-  uint32_t s_lseqnc[kSegCapExtra];   // l_seq | n_cigar << 16
-  int32_t s_rec[kSegCapExtra];       // record index
-  // the M op of the record's mate that this segment can overlap (stitch; phase 1 cuts a
-  // segment wherever the mate's next M op starts, so there is at most one): x = its start
-  // relative to the window start, y = its length | this record is the one that found its
-  // mate << 17 | has a mate << 18, z = mate payload offset, w = mate l_seq | n_cigar << 16;
-  // s_mx = read index of its first base | mate qdelta << 16
-  uint4 s_mate[kSegCapExtra];
-  uint32_t s_mx[kSegCapExtra];
-  // where the unit loader finds the pass bits of the segment's first unit (the segment record's
-  // own offset field says where its quals are, which the overlap groups need): byte offset from
-  // the first unit's bases << 5 | bit shift
-  uint32_t s_qp[kSegCapExtra];
-  uint8_t qthr[96];             // KernelParams::qthr, "never" clamped to 96
-  // stitch: the unit slots of this round with positions that the record's mate covers too and
-  // that this record has to decide (it found its mate); filled by phase 1 (0xffff: void)
-  uint16_t ovl[kUnitCap];
+struct SegRec {
+  int32_t rec[kSegCap];  // stitch: record index of the segment (to name the record of a data error)
 };
-struct NoExtra {};
+struct NoRec {};
 
 // One M-segment of the current round, with everything a unit needs precomputed by the lane
 // that walked the CIGAR:
@@ -224,63 +198,17 @@ struct NoExtra {};
 //   y  0..2 address bits 32..34 | 3..5 nibble shift | 6 strand slot | 8..12 first valid
 //      position of the first unit | 13..17 last valid position of the last unit |
 //      24..29 number of units - 1
-//   z  0..14 first unit slot | 16..21 first window unit | 24..25 qual byte shift
-//   w  (qual address of the first unit, 4-byte aligned) - (base address above); unit u reads
-//      36 bytes at x + w + 32u
-template <bool EXTRA>
+//   z  0..14 first unit slot | 16..21 first window unit | 24..28 bit shift of the unit's pass bits
+//   w  (address of the dword with the first unit's first pass bit) - (base address above); unit u
+//      reads 8 bytes at x + w + 4u (stitch: 16 bytes - pass, drop, pass, drop - at x + w + 8u)
+template <bool STITCH>
 struct __align__(16) BlockSharedT {
   uint32_t cnt[kPlanes * kStride];
-  uint4 seg[seg_cap<EXTRA>()];
-  typename std::conditional<EXTRA, SegExtra, NoExtra>::type ex;
+  uint4 seg[kSegCap];
+  typename std::conditional<STITCH, SegRec, NoRec>::type ex;
   uint16_t owner[kUnitCap];     // unit slot -> segment
-  unsigned long long n_alloc[2];  // segments << 32 | overlap-list entries << 16 | units handed out this round (by round parity)
-  uint32_t more[2];               // a thread still has records of this window after this round (by round parity)
+  unsigned long long n_alloc[2];  // segments << 32 | units handed out this round (by round parity)
 };
-
-// Reference position -> read index of record `c` (mate lookup for the overlap rule).
-// Returns -1 when no M op of the record covers ref position `rp`.
-__device__ int32_t read_index_at(const ReadCore& c, const uint8_t* blob, int32_t rp) {
-  const uint32_t* cg = (const uint32_t*)(blob + (uint64_t)c.blob * 8);
-  int32_t r = c.pos, q = 0;
-  for (uint32_t k = 0; k < c.n_cigar; k++) {
-    uint32_t op = cg[k] & 15u;
-    int32_t len = (int32_t)(cg[k] >> 4);
-    if (op == 0) {
-      if (rp >= r && rp < r + len) return q + (rp - r);
-      r += len; q += len;
-    } else if (op == 1 || op == 4) {
-      q += len;
-    } else if (op == 2 || op == 3) {
-      r += len;
-    } else if (op != 5) {
-      break;
-    }
-    if (r > rp) break;
-  }
-  return -1;
-}
-
-// The same walk on window-relative coordinates: `rel` = record start - window start.
-__device__ int32_t read_index_rel(int32_t rel, uint32_t n_cigar, const uint8_t* payload, int32_t rp) {
-  const uint32_t* cg = (const uint32_t*)payload;
-  int32_t r = rel, q = 0;
-  for (uint32_t k = 0; k < n_cigar; k++) {
-    uint32_t op = cg[k] & 15u;
-    int32_t len = (int32_t)(cg[k] >> 4);
-    if (op == 0) {
-      if (rp >= r && rp < r + len) return q + (rp - r);
-      r += len; q += len;
-    } else if (op == 1 || op == 4) {
-      q += len;
-    } else if (op == 2 || op == 3) {
-      r += len;
-    } else if (op != 5) {
-      break;
-    }
-    if (r > rp) break;
-  }
-  return -1;
-}
 
 __device__ __forceinline__ uint32_t clipped_qual(uint32_t q, int32_t b, int32_t l_seq, int32_t clip) {
   // clipQuals (pileup_support.go:51-69)
@@ -322,45 +250,29 @@ __device__ __forceinline__ bool seg_extent(const SegIn& g, uint32_t wlen, int32_
   return true;
 }
 
-template <bool EXTRA, bool QP>
-__device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, uint32_t us, const SegIn& g,
+template <int QM, bool STITCH>
+__device__ __forceinline__ void write_seg(BlockSharedT<STITCH>& S, uint32_t idx, uint32_t us, const SegIn& g,
                                           int32_t s1, int32_t e1, uint32_t jlo, uint32_t U, uint32_t blob,
-                                          uint32_t lseqnc, uint32_t qdelta, uint32_t sslot, int32_t rec,
-                                          uint4 minfo, uint32_t mx) {
-  // byte offsets from the record's base part [cigar padded to even][seq 4*Ur]; its quals
-  // start 8 * qdelta bytes after it
+                                          uint32_t lseqnc, uint32_t sslot, [[maybe_unused]] int32_t rec) {
+  // byte offsets from the record's base part [cigar padded to even][seq 4*Ur][bits]
   const uint32_t nc = lseqnc >> 16;
   const int32_t cigb = (int32_t)(((nc + 1) & ~1u) * 4);
   const int32_t d = g.q0 - g.sref;                       // read index of window position 0
-  const int32_t b_first = d + (int32_t)(jlo * 32);       // read index of the first unit's base 0
-  const int32_t qo = (int32_t)(qdelta * 8u) + b_first;   // >= -23: the payload buffer starts with a pad
-  const int32_t so = cigb + (b_first >> 1);              // >= -8
+  const int32_t b_first = d + (int32_t)(jlo * 32);       // read index of the first unit's base 0 (>= -31)
+  const int32_t so = cigb + (b_first >> 1);              // >= -16: the payload buffer starts with a pad
   const uint64_t sa = (uint64_t)((int64_t)((uint64_t)blob * 8) + (int64_t)(so & ~3));  // so may be < 0
   const uint32_t noff = 2u * ((uint32_t)so & 3u) + ((uint32_t)d & 1u);
   uint4 r;
   r.x = (uint32_t)sa;
   r.y = (uint32_t)(sa >> 32) | (noff << 3) | (sslot << 6) | (((uint32_t)s1 & 31u) << 8) |
         (((uint32_t)(e1 - 1) & 31u) << 13) | ((U - 1) << 24);
-  // pass bits: bit b_first of the record's bit string, which lies behind its packed bases (4 bytes
-  // per 8-base unit of the whole read); b_first may be < 0 (>= -31)
-  [[maybe_unused]] const int32_t mb = (cigb + 4 * (int32_t)(((lseqnc & 0xffffu) + 7u) >> 3)) * 8 + b_first;
-  if constexpr (QP && !EXTRA) {
-    r.z = us | (jlo << 16) | (((uint32_t)mb & 31u) << 24);
-    r.w = (uint32_t)(((mb >> 5) << 2) - (so & ~3));
-  } else {
-    r.z = us | (jlo << 16) | (((uint32_t)qo & 3u) << 24);
-    r.w = (uint32_t)((qo & ~3) - (so & ~3));
-  }
+  // per-base bits: bit b_first of the record's bit string, which lies behind its packed bases (4
+  // bytes per 8-base unit of the whole read); one dword per 32 bases, two (pass, drop) when stitching
+  r.z = us | (jlo << 16) | (((uint32_t)b_first & 31u) << 24);
+  const int32_t bits0 = cigb + 4 * (int32_t)(((lseqnc & 0xffffu) + 7u) >> 3);
+  r.w = QM == 0 ? 0u : (uint32_t)(bits0 + (b_first >> 5) * (QM == 3 ? 8 : 4) - (so & ~3));
   S.seg[idx] = r;
-  if constexpr (EXTRA) {
-    S.ex.s_ref[idx] = g.sref;
-    S.ex.s_lenq0[idx] = (uint32_t)g.len | ((uint32_t)g.q0 << 16);
-    S.ex.s_lseqnc[idx] = lseqnc;
-    S.ex.s_rec[idx] = rec;
-    S.ex.s_mate[idx] = minfo;
-    S.ex.s_mx[idx] = mx;
-    if constexpr (QP) S.ex.s_qp[idx] = ((uint32_t)(((mb >> 5) << 2) - (so & ~3)) << 5) | ((uint32_t)mb & 31u);
-  }
+  if constexpr (STITCH) S.ex.rec[idx] = rec;
   for (uint32_t i = 0; i < U; i++) S.owner[us + i] = (uint16_t)idx;
 }
 
@@ -369,87 +281,57 @@ __device__ __forceinline__ void write_seg(BlockSharedT<EXTRA>& S, uint32_t idx, 
 // packed (segments << 32 | units) counter, so unit slots grow with the segment index.
 // Returns false for a lane whose segments did not fit this round (it got neither): the
 // caller keeps its cursor and retries next round.
-// Stitching: the units of a segment (window positions [s1, e1), first unit jlo) with positions
-// that the M op of the mate described by mi covers too, if this record is the one that decides
-// them (it found its mate in the table, pileup.go:409-430): first such unit relative to jlo, count.
-__device__ __forceinline__ uint32_t overlap_units(int32_t s1, int32_t e1, uint32_t jlo, const uint4& mi, uint32_t& first) {
-  first = 0;
-  if ((mi.y & 0x60000u) != 0x60000u) return 0u;  // has a mate, and found it
-  const int32_t ms = (int32_t)mi.x, me = ms + (int32_t)(mi.y & 0xffffu);
-  const int32_t lo = s1 > ms ? s1 : ms, hi = e1 < me ? e1 : me;
-  if (hi <= lo) return 0u;
-  first = ((uint32_t)lo >> 5) - jlo;
-  return (((uint32_t)(hi - 1) >> 5) - jlo) - first + 1u;
-}
-
-template <bool EXTRA, bool STITCH, bool QP>
-__device__ __forceinline__ bool emit_wave(BlockSharedT<EXTRA>& S, bool wantA, const SegIn& A, bool wantB,
+template <int QM, bool STITCH>
+__device__ __forceinline__ bool emit_wave(BlockSharedT<STITCH>& S, bool wantA, const SegIn& A, bool wantB,
                                           const SegIn& B, uint32_t wlen, uint32_t blob, uint32_t lseqnc,
-                                          uint32_t qdelta, uint32_t sslot, int32_t rec, uint32_t par, uint4 miA,
-                                          uint32_t mxA, uint4 miB, uint32_t mxB) {
+                                          uint32_t sslot, int32_t rec, uint32_t par) {
   int32_t s1A, e1A, s1B, e1B;
   uint32_t jloA, UA, jloB, UB;
   const bool realA = seg_extent(A, wlen, s1A, e1A, jloA, UA) && wantA;  // clipped-away segments need no slot
   const bool realB = seg_extent(B, wlen, s1B, e1B, jloB, UB) && wantB;
   if (!realA) UA = 0;
   if (!realB) UB = 0;
-  uint32_t fA = 0, fB = 0, nA = 0, nB = 0;  // stitch: entries of the overlap list
-  if constexpr (STITCH) {
-    if (realA) nA = overlap_units(s1A, e1A, jloA, miA, fA);
-    if (realB) nB = overlap_units(s1B, e1B, jloB, miB, fB);
-  }
-  const uint32_t nseg = (realA ? 1u : 0u) + (realB ? 1u : 0u), U = UA + UB, nov = nA + nB;
-  // inclusive prefix sums of (segments, list entries, units) over the wave, packed as
-  // segments << 23 | entries << 13 | units (a wave adds at most 128 segments, 128 x 6 entries
-  // and 128 x (kW/32 + 1) units: no carry between the fields)
-  const uint32_t mine = (nseg << 23) | (nov << 13) | U;
+  const uint32_t nseg = (realA ? 1u : 0u) + (realB ? 1u : 0u), U = UA + UB;
+  // inclusive prefix sums of (segments, units) over the wave, packed as segments << 16 | units
+  // (a wave adds at most 128 segments and 128 x (kW/32 + 1) units: no carry between the fields)
+  const uint32_t mine = (nseg << 16) | U;
   const uint32_t incl = wave_inclusive_scan(mine);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   unsigned long long base = 0;
   if ((threadIdx.x & 63) == 0 && total != 0)
-    base = atomicAdd(&S.n_alloc[par], ((unsigned long long)(total >> 23) << 32) | (((total >> 13) & 0x3ffu) << 16) | (total & 0x1fffu));
+    base = atomicAdd(&S.n_alloc[par], ((unsigned long long)(total >> 16) << 32) | (total & 0xffffu));
   const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
   const uint32_t base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
   const uint32_t excl = incl - mine;
-  // (units and entries handed out in a round stay below 2^16 each: 512 lanes x 2 x 33)
-  const uint32_t idx = base_s + (excl >> 23), us = (base_lo & 0xffffu) + (excl & 0x1fffu);
-  const bool ok = idx + nseg <= (uint32_t)seg_cap<EXTRA>() && us + U <= (uint32_t)kUnitCap;
+  // (units handed out in a round stay below 2^16... 512 lanes x 2 x 33; the counter's low word
+  // cannot carry into the segments)
+  const uint32_t idx = base_s + (excl >> 16), us = base_lo + (excl & 0xffffu);
+  const bool ok = idx + nseg <= (uint32_t)kSegCap && us + U <= (uint32_t)kUnitCap;
   if (ok) {
-    if (realA) write_seg<EXTRA, QP>(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, qdelta, sslot, rec, miA, mxA);
-    if (realB)
-      write_seg<EXTRA, QP>(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, qdelta, sslot, rec, miB, mxB);
+    if (realA) write_seg<QM, STITCH>(S, idx, us, A, s1A, e1A, jloA, UA, blob, lseqnc, sslot, rec);
+    if (realB) write_seg<QM, STITCH>(S, idx + (realA ? 1u : 0u), us + UA, B, s1B, e1B, jloB, UB, blob, lseqnc, sslot, rec);
   } else {
     for (uint32_t i = us; i < (uint32_t)kUnitCap && i - us < U; i++) S.owner[i] = 0xffffu;
-  }
-  if constexpr (STITCH) {
-    // every entry is one of the lane's units, so entries run behind unit slots: a lane whose
-    // units fit has room for its entries too
-    uint32_t o = (base_lo >> 16) + ((excl >> 13) & 0x3ffu);
-    if (ok) {
-      for (uint32_t i = 0; i < nA; i++) S.ex.ovl[o++] = (uint16_t)(us + fA + i);
-      for (uint32_t i = 0; i < nB; i++) S.ex.ovl[o++] = (uint16_t)(us + UA + fB + i);
-    } else {
-      for (uint32_t i = 0; i < nov && o < (uint32_t)kUnitCap; i++) S.ex.ovl[o++] = 0xffffu;
-    }
   }
   return ok;
 }
 
-// One unit in flight: the loaded bytes and everything processing needs, so that the plain
-// path does not touch the segment list again.
-// QM: what the unit brings of the quals. 0 nothing (min_base_qual 0 without stitching: every base
-// passes), 2 the 32 pass bits the packer left behind the bases (KernelParams.qpass).  (1 was the
-// 32 quals themselves, 36 bytes: the plain pass compared them with min_base_qual and worked out
-// the clip masks itself until the packers took that over; 5.73 -> 4.67 ms on chr1 30x
-// -min-base-qual 20.  The overlap groups of stitched runs still load quals: they need the values.)
-template <int QM, bool STITCH = false>
+// One unit in flight: the loaded bytes and everything processing needs, so that processing does
+// not touch the segment list again.
+// QM: what the unit brings beside its bases.  0 nothing (min_base_qual 0 without stitching: every
+// base passes), 2 the 32 pass bits the packer left behind the bases (KernelParams.qpass; quality
+// rule and clip applied there), 3 (stitch) pass and drop bits, the outcome of the pair rule
+// worked out once per job by stitch_resolve_kernel.  (1 was the 32 quals themselves, 36 bytes: the
+// kernel compared them with min_base_qual and worked out the clip masks itself until the packers
+// took that over; 5.73 -> 4.67 ms on chr1 30x -min-base-qual 20.)
+template <int QM>
 struct UnitLoad {
   uint32_t sd[5];                  // 20 bytes covering the unit's 32 packed bases
-  uint32_t qd[QM == 2 ? 2 : 1];    // 8 bytes covering the unit's pass bits
+  uint32_t qd[QM == 3 ? 4 : QM == 2 ? 2 : 1];  // the dwords covering the unit's pass (and drop) bits
   uint32_t mask;                   // valid positions of the unit
-  uint32_t meta;                   // 0..5 window unit | 6..8 nibble shift | 9..10 qual byte shift |
-                                   // 11 strand slot | 16 active | 17..21 bit shift of the pass bits
-  uint32_t seg;                    // segment (stitched / clipped paths)
+  uint32_t meta;                   // 0..5 window unit | 6..8 nibble shift | 11 strand slot | 16 active |
+                                   // 17..21 bit shift of the pass bits
+  uint32_t seg;                    // segment (stitch: to name the record of a data error)
 };
 
 // Loads are issued unconditionally (inactive lanes read the start of the payload buffer) so
@@ -474,23 +356,9 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t t, uint32_t T, uint32_t R) 
   return t < T ? t : T;
 }
 
-// Stitching: the positions of unit jj of segment s that the record's mate covers too (every
-// segment overlaps at most one M op of the mate: phase 1 cuts them that way), and whether this
-// record is the one that decides them (it found its mate in the table, pileup.go:409-430).
-template <class SH>
-__device__ __forceinline__ uint32_t mate_overlap(const SH& S, uint32_t s, uint32_t jj, bool& second) {
-  const uint2 mi = *(const uint2*)&S.ex.s_mate[s];
-  second = (mi.y & 0x20000u) != 0;
-  if (!(mi.y & 0x40000u)) return 0u;
-  const int32_t lo = (int32_t)mi.x - (int32_t)(32u * jj), hi = lo + (int32_t)(mi.y & 0xffffu);
-  const int32_t l2 = lo > 0 ? lo : 0, h2 = hi < 32 ? hi : 32;
-  if (h2 <= l2) return 0u;
-  return h2 - l2 >= 32 ? 0xffffffffu : ((1u << (h2 - l2)) - 1u) << l2;
-}
-
-template <int QM, bool STITCH, bool EXTRA>
-__device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<EXTRA>& S, uint32_t t,
-                                           uint32_t T, UnitLoad<QM, STITCH>& L) {
+template <int QM, bool STITCH>
+__device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSharedT<STITCH>& S, uint32_t t,
+                                           uint32_t T, UnitLoad<QM>& L) {
   bool in = t < T;
   uint32_t s = S.owner[in ? t : 0];
   if (s == 0xffffu) { in = false; s = 0; }
@@ -501,193 +369,27 @@ __device__ __forceinline__ void issue_unit(const KernelParams& P, const BlockSha
                   (u == ((r.y >> 24) & 0x3fu) ? 0xffffffffu >> (31u - ((r.y >> 13) & 31u)) : 0xffffffffu);
   L.mask = in ? mask : 0u;
   L.seg = s;
-  uint32_t qpo = r.w, qps = (r.z >> 24) & 31u;  // QM == 2: where the pass bits are
-  if constexpr (QM == 2 && EXTRA) {
-    const uint32_t v = S.ex.s_qp[s];
-    qpo = v >> 5;
-    qps = v & 31u;
-  }
-  L.meta = (in ? jj | 0x10000u : 0u) | (((r.y >> 3) & 7u) << 6) |
-           (QM == 2 ? qps << 17 : ((r.z >> 24) & 3u) << 9) | (((r.y >> 6) & 1u) << 11);
+  L.meta = (in ? jj | 0x10000u : 0u) | (((r.y >> 3) & 7u) << 6) | (((r.z >> 24) & 31u) << 17) | (((r.y >> 6) & 1u) << 11);
   uint64_t off = (((uint64_t)(r.y & 7u) << 32) | r.x) + 16u * u;
   if (!in) off = 0;
   const uint8_t* sp = P.blob + off;
   if constexpr (QM == 2) {
-    const uint8_t* mp = sp + (in ? (int64_t)(int32_t)qpo - 12 * (int64_t)u : 0);  // (sp moves 16 bytes a unit, the bits 4)
+    const uint8_t* mp = sp + (in ? (int64_t)(int32_t)r.w - 12 * (int64_t)u : 0);  // (sp moves 16 bytes a unit, the bits 4)
     const u32x2a m0 = *(const u32x2a*)mp;
     L.qd[0] = m0.x;
     L.qd[1] = m0.y;
+  }
+  if constexpr (QM == 3) {
+    const uint8_t* mp = sp + (in ? (int64_t)(int32_t)r.w - 8 * (int64_t)u : 0);  // (... pass + drop bits 8)
+    const u32x4a m0 = *(const u32x4a*)mp;
+    L.qd[0] = m0.x; L.qd[1] = m0.y; L.qd[2] = m0.z; L.qd[3] = m0.w;
   }
   const u32x4a s0 = *(const u32x4a*)sp;
   L.sd[4] = *(const uint32_t*)(sp + 16);
   L.sd[0] = s0.x; L.sd[1] = s0.y; L.sd[2] = s0.z; L.sd[3] = s0.w;
 }
 
-// ---- stitching: the positions both mates cover (addReadPair, pileup.go:406-446)
-// Such positions are left out by the plain pass and decided here, 8 at a time: work item w of the
-// round's overlap list = group (w & 3) of the unit in entry (w >> 2).  A lane holds the 8 bases
-// and 8 quals of the record and of its mate over the group: 10 dwords in flight.
-struct OvGroup {
-  uint32_t x0, x1;        // own packed bases: dwords m, m+1 of the unit's 20 bytes
-  uint32_t q0, q1, q2;    // own quals: dwords 2m .. 2m+2 of the unit's 36 bytes
-  uint32_t m0, m1;        // the mate's bases over the same positions
-  uint32_t n0, n1, n2;    // ... and quals
-  uint32_t ovg;           // positions of the group to decide (8 bits); 0: nothing to do
-  uint32_t sh;            // 0..4 own nibble shift x 4 | 5..6 own qual byte shift | 8..12 mate nibble shift x 4 | 13..14 mate qual byte shift
-  uint32_t lds_off;       // byte offset in the planes of the group's position 0, strand slot included
-  uint32_t seg;
-  int32_t pw;             // window position of the group's first position
-};
-
-template <class SH>
-__device__ __forceinline__ void issue_ov_group(const KernelParams& P, const SH& S, uint32_t w, uint32_t n_ovl,
-                                               uint32_t T, uint32_t cpo, OvGroup& G) {
-  const uint32_t m = w & 3u;
-  uint32_t t = (w >> 2) < n_ovl ? (uint32_t)S.ex.ovl[w >> 2] : T;
-  bool in = t < T;
-  uint32_t s = S.owner[in ? t : 0];
-  if (s == 0xffffu) { in = false; s = 0; }
-  const uint4 r = S.seg[s];
-  const uint32_t u = t - (r.z & 0x7fffu);
-  const uint32_t jj = ((r.z >> 16) & 0x3fu) + u;
-  const uint32_t mask = (u == 0 ? 0xffffffffu << ((r.y >> 8) & 31u) : 0xffffffffu) &
-                        (u == ((r.y >> 24) & 0x3fu) ? 0xffffffffu >> (31u - ((r.y >> 13) & 31u)) : 0xffffffffu);
-  bool second = false;
-  const uint32_t ov = in ? mate_overlap(S, s, jj, second) & mask : 0u;
-  const uint32_t ovg = second ? (ov >> (8u * m)) & 0xffu : 0u;
-  G.ovg = ovg;
-  G.seg = s;
-  G.pw = (int32_t)((4u * jj + m) * 8u);
-  G.lds_off = (jj + cpo + ((r.y >> 6) & 1u) * (uint32_t)kStride + 8u * m * (uint32_t)kSub) * 4u;
-  // own bytes (see issue_unit): bases at off + 16u, quals at off + r.w + 32u
-  const uint64_t off = (((uint64_t)(r.y & 7u) << 32) | r.x) + 16u * u;
-  const uint8_t* sp = P.blob + (ovg ? off + 4u * m : 0);
-  const uint8_t* qp = P.blob + (ovg ? off + (int64_t)(int32_t)r.w + 16 * (int64_t)u + 8u * m : 0);
-  // the mate's: read index of the unit's position 0, then as for the record itself
-  const uint4 mi4 = S.ex.s_mate[s];
-  const uint32_t mx = S.ex.s_mx[s];
-  const int32_t mi0 = (int32_t)(32u * jj) - (int32_t)mi4.x + (int32_t)(mx & 0xffffu);
-  const int32_t mcig = (int32_t)((((mi4.w >> 16) + 1u) & ~1u) * 4);
-  const int32_t qo = (int32_t)((mx >> 16) * 8u) + mi0;  // may be < 0 by less than the buffer's leading pad
-  const int32_t so = mcig + (mi0 >> 1);
-  G.sh = (((r.y >> 3) & 7u) << 2) | (((r.z >> 24) & 3u) << 5) |
-         ((2u * ((uint32_t)so & 3u) + ((uint32_t)mi0 & 1u)) << 10) | (((uint32_t)qo & 3u) << 13);
-  const uint8_t* mb = P.blob + (ovg ? (uint64_t)mi4.z * 8 : 64);
-  const uint8_t* mqp = mb + (ovg ? (qo & ~3) + 8 * (int32_t)m : 0);
-  const uint8_t* msp = mb + (ovg ? (so & ~3) + 4 * (int32_t)m : 0);
-  const u32x2a a = *(const u32x2a*)sp;
-  const u32x3a b = *(const u32x3a*)qp;
-  const u32x2a c = *(const u32x2a*)msp;
-  const u32x3a d = *(const u32x3a*)mqp;
-  G.x0 = a.x; G.x1 = a.y;
-  G.q0 = b.x; G.q1 = b.y; G.q2 = b.z;
-  G.m0 = c.x; G.m1 = c.y;
-  G.n0 = d.x; G.n1 = d.y; G.n2 = d.z;
-}
-
-// Equal bases: the base if qualSumTable[q0][q1] >= minBaseQual (a per-row threshold, qthr), else
-// depth only; X stays X; different bases: X (pileup.go:409-430).
-template <bool CLIP, class SH>
-__device__ __forceinline__ void process_ov_group(const KernelParams& P, SH& B, const OvGroup& G) {
-  const uint32_t ovg = G.ovg;
-  if (!ovg) return;
-  constexpr uint32_t M1 = 0x11111111u, H = 0x80808080u;
-  const uint32_t sw = __builtin_amdgcn_alignbit(G.x1, G.x0, G.sh & 0x1cu);
-  const uint32_t qsh = (G.sh >> 5) & 3u;
-  const uint32_t qlo = __builtin_amdgcn_alignbyte(G.q1, G.q0, qsh), qhi = __builtin_amdgcn_alignbyte(G.q2, G.q1, qsh);
-  const uint32_t msw = __builtin_amdgcn_alignbit(G.m1, G.m0, (G.sh >> 8) & 0x1cu);
-  const uint32_t msh = (G.sh >> 13) & 3u;
-  const uint32_t mqlo = __builtin_amdgcn_alignbyte(G.n1, G.n0, msh), mqhi = __builtin_amdgcn_alignbyte(G.n2, G.n1, msh);
-  // plane codes of the record's bases (Seq8ToEnumTable: one-hot nibble -> log2, anything else X = 4)
-  const uint32_t t1 = sw >> 1;
-  const uint32_t lg = (t1 & 0x77777777u) - ((sw >> 3) & M1);
-  const uint32_t xx = sw ^ t1, a = sw & t1;
-  const uint32_t oh = (xx ^ (xx >> 2)) & ~(a | (a >> 2)) & M1;
-  const uint32_t oh3 = oh | (oh << 1);
-  const uint32_t cpass = (lg & oh3) + ((oh ^ M1) << 2);
-  const uint32_t cf = 0x44444444u | oh;  // failing: base -> depth-only (5), X stays X (4)
-  // nibble k of dn != 0 <=> the reads disagree at position k
-  const uint32_t dn = msw ^ sw;
-  const uint32_t eqn = ~(dn | (dn >> 1) | (dn >> 2) | (dn >> 3)) & M1;
-  uint32_t ovn = (ovg | (ovg << 12)) & 0x000f000fu;  // 8 bits -> one flag per nibble
-  ovn = (ovn | (ovn << 6)) & 0x03030303u;
-  ovn = (ovn | (ovn << 3)) & M1;
-  uint32_t cw = 0x44444444u, vmask = ovg;
-  bool fast = !CLIP;
-  if constexpr (!CLIP) {
-    // a qual >= 96 at an agreeing position indexes qualPassTable out of range (a Go runtime
-    // panic in the reference): those groups take the per-base loop below
-    uint32_t blo = ((((qlo & 0x7f7f7f7fu) + 0x20202020u) | qlo) | (((mqlo & 0x7f7f7f7fu) + 0x20202020u) | mqlo)) & H;
-    uint32_t bhi = ((((qhi & 0x7f7f7f7fu) + 0x20202020u) | qhi) | (((mqhi & 0x7f7f7f7fu) + 0x20202020u) | mqhi)) & H;
-    blo = (blo | (blo >> 4)) & 0x08800880u;
-    blo = (blo | (blo >> 8)) & 0x00088880u;
-    bhi = (bhi | (bhi >> 4)) & 0x08800880u;
-    bhi = (bhi | (bhi >> 8)) & 0x00088880u;
-    fast = ((((blo >> 7) | (bhi << 9)) & eqn & ovn) == 0);
-  }
-  if (fast) {
-    // the pair passes iff mate qual >= qthr[own qual] (qualSumTable row, qual.go:35-77): 8 byte
-    // lookups, then a SWAR byte compare
-    const uint8_t* const qt = B.ex.qthr;
-    const uint32_t tlo = (uint32_t)qt[qlo & 0xffu] | ((uint32_t)qt[(qlo >> 8) & 0xffu] << 8) |
-                         ((uint32_t)qt[(qlo >> 16) & 0xffu] << 16) | ((uint32_t)qt[qlo >> 24] << 24);
-    const uint32_t thi = (uint32_t)qt[qhi & 0xffu] | ((uint32_t)qt[(qhi >> 8) & 0xffu] << 8) |
-                         ((uint32_t)qt[(qhi >> 16) & 0xffu] << 16) | ((uint32_t)qt[qhi >> 24] << 24);
-    // (thresholds <= 96; the mask keeps a stray lookup of a qual >= 96 at a position that does
-    // not matter from borrowing into its neighbour)
-    uint32_t plo = ((mqlo | H) - (tlo & 0x7f7f7f7fu)) & H;
-    uint32_t phi = ((mqhi | H) - (thi & 0x7f7f7f7fu)) & H;
-    plo = (plo | (plo >> 4)) & 0x08800880u;
-    plo = (plo | (plo >> 8)) & 0x00088880u;
-    phi = (phi | (phi >> 4)) & 0x08800880u;
-    phi = (phi | (phi >> 8)) & 0x00088880u;
-    const uint32_t p2 = (plo >> 7) | (phi << 9);
-    const uint32_t p15 = (p2 << 4) - p2, eq15 = (eqn << 4) - eqn;
-    cw = (eq15 & ((cpass & p15) | (cf & ~p15))) | (~eq15 & 0x44444444u);
-  } else {
-    const uint32_t sg = G.seg;
-    int32_t b0 = 0, lseq = 0;
-    if constexpr (CLIP) {  // clipQuals (pileup_support.go:51-69) on both reads
-      b0 = (int32_t)(B.ex.s_lenq0[sg] >> 16) + (G.pw - B.ex.s_ref[sg]);
-      lseq = (int32_t)(B.ex.s_lseqnc[sg] & 0xffffu);
-    }
-    const uint4 mi4 = B.ex.s_mate[sg];
-    const int32_t mls = (int32_t)(mi4.w & 0xffffu);
-    const int32_t mi0 = G.pw - (int32_t)mi4.x + (int32_t)(B.ex.s_mx[sg] & 0xffffu);
-#pragma unroll 1
-    for (int k = 0; k < 8; k++) {
-      if (!((ovg >> k) & 1u)) continue;
-      uint32_t q = ((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu;
-      uint32_t mq = ((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu;
-      if constexpr (CLIP) {
-        q = clipped_qual(q, b0 + k, lseq, P.clip);
-        mq = clipped_qual(mq, mi0 + k, mls, P.clip);
-      }
-      uint32_t code = 4u;  // the reads disagree: X
-      if ((eqn >> (4 * k)) & 1u) {
-        if (q >= 96u || mq >= 96u) {
-          atomicMin(&P.err->read, B.ex.s_rec[sg]);
-          vmask &= ~(1u << k);
-          continue;
-        }
-        code = ((mq >= (uint32_t)B.ex.qthr[q] ? cpass : cf) >> (4 * k)) & 7u;
-      }
-      cw = (cw & ~(0xfu << (4 * k))) | (code << (4 * k));
-    }
-  }
-  char* const lds = (char*)B.cnt;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint32_t c = (cw >> (4 * k)) & 7u;
-    const uint32_t val = (vmask >> k) & 1u;
-#ifdef BP_X_NOATOMIC
-    if (val > 1u)
-#endif
-    atomicAdd((uint32_t*)(lds + c * (uint32_t)(2 * kStride * 4) + G.lds_off + k * kSub * 4), val);
-  }
-}
-
-// The plain path: no stitching.  The unit's 32 positions are handled as 4 groups of 8; the 8
+// The unit's 32 positions are handled as 4 groups of 8; the 8
 // plane codes of a group are computed together on the nibble-packed bases (SWAR), so the
 // per-base cost is two extractions, one multiply-add and the LDS atomic.
 //   code c: A 0, C 1, G 2, T 3, X 4, depth-only 5  ->  plane 2c + strand slot
@@ -695,16 +397,27 @@ __device__ __forceinline__ void process_ov_group(const KernelParams& P, SH& B, c
 // (log2 = its code); every other value is X.  A base failing the quality rule goes to the
 // depth-only planes, X is counted regardless (addBase, pileup.go:223-231).
 //
-// Stitched runs take the same path: the codes of a group are computed as if every base stood
-// alone, and only the positions the record's mate also covers are patched afterwards
-// (addReadPair, pileup.go:406-446): the record that was stored first drops them, the one that
-// found its mate decides them from both reads (equal bases: qualSumTable threshold, else X).
+// Stitched runs take the same path.  What addReadPair (pileup.go:406-446) decides where both
+// reads of a pair cover a position was written into the payloads by stitch_resolve_kernel: the
+// read stored first has its drop bits set there (the position is counted once, with the other
+// read), the read that found its mate carries the outcome in its bases (X where the reads
+// disagree) and pass bits (the qualSumTable rule where they agree).  Pass and drop both set marks a
+// quality >= 96 at an agreeing position, where the reference's table lookup panics: reported with
+// the record's index when a window gets there, as the reference would fail there.
 template <int QM, class SH>
-__device__ __forceinline__ void process_unit_plain(SH& B, const UnitLoad<QM, false>& L, uint32_t cpo) {
+__device__ __forceinline__ void process_unit_plain(const KernelParams& P, SH& B, const UnitLoad<QM>& L, uint32_t cpo) {
   constexpr uint32_t M1 = 0x11111111u;
   const uint32_t meta = L.meta;
   const uint32_t jj = meta & 0x3fu;
   uint32_t vmask = L.mask;  // positions still to be counted
+  [[maybe_unused]] uint32_t pass32 = 0xffffffffu;
+  if constexpr (QM == 2) pass32 = __builtin_amdgcn_alignbit(L.qd[1], L.qd[0], (meta >> 17) & 31u);
+  if constexpr (QM == 3) {
+    pass32 = __builtin_amdgcn_alignbit(L.qd[2], L.qd[0], (meta >> 17) & 31u);
+    const uint32_t drop32 = __builtin_amdgcn_alignbit(L.qd[3], L.qd[1], (meta >> 17) & 31u);
+    if (pass32 & drop32 & vmask) atomicMin(&P.err->read, B.ex.rec[L.seg]);
+    vmask &= ~drop32;
+  }
   const uint32_t* const x = L.sd;  // base k of a dword at bits 4k (the packer stores it that way)
   const uint32_t nsh = (meta >> 4) & 0x1cu;  // 4 * nibble shift
   const uint32_t cbase = (jj + cpo + ((meta >> 11) & 1u) * (uint32_t)kStride) * 4u;
@@ -719,9 +432,9 @@ __device__ __forceinline__ void process_unit_plain(SH& B, const UnitLoad<QM, fal
     const uint32_t oh = (xx ^ (xx >> 2)) & ~(a | (a >> 2)) & M1;      // exactly one bit set
     const uint32_t oh3 = oh | (oh << 1);
     uint32_t cw = (lg & oh3) + ((oh ^ M1) << 2);                      // one-hot ? log2 : 4 (X)
-    if constexpr (QM == 2) {
-      // the packer's pass bits (quality rule and clip already applied): 8 bits -> bit 4k
-      uint32_t pn = (__builtin_amdgcn_alignbit(L.qd[1], L.qd[0], (meta >> 17) & 31u) >> (8 * m)) & 0xffu;
+    if constexpr (QM != 0) {
+      // the pass bits (quality rule, clip and pair rule already applied): 8 bits -> bit 4k
+      uint32_t pn = (pass32 >> (8 * m)) & 0xffu;
       pn = (pn | (pn << 12)) & 0x000f000fu;
       pn = (pn | (pn << 6)) & 0x03030303u;
       pn = (pn | (pn << 3)) & M1;
@@ -775,53 +488,6 @@ __device__ __forceinline__ bool next_m_op(const uint32_t* cg, uint32_t cg0, uint
   return false;
 }
 
-// Stitching, mate with more than one CIGAR op: the next piece of the record's M ops, cut so
-// that at most one M op of the mate overlaps it (a piece ends where the mate's following M op
-// starts).  (rs, rl, rq) = the part of the current own M op not handed out yet; the mate's
-// CIGAR (mn ops at mcg, first base at window position mrel) is walked again for every piece:
-// such mates are few and their CIGARs short.  (ms, ml, mq0) = the mate M op for this piece
-// (ml = 0: none).
-__device__ __forceinline__ bool next_piece(const uint32_t* cg, uint32_t cg0, uint32_t cg1, uint32_t cg2,
-                                           uint32_t n_cigar, uint32_t wlen, uint32_t& c, int32_t& r, int32_t& q,
-                                           int32_t& rs, int32_t& rl, int32_t& rq, const uint32_t* mcg,
-                                           const u32x4a& m4, uint32_t mn, int32_t mrel, int32_t& sref, int32_t& slen,
-                                           int32_t& sq0, int32_t& ms, int32_t& ml, int32_t& mq0) {
-  if (rl == 0 && !next_m_op(cg, cg0, cg1, cg2, n_cigar, wlen, c, r, q, rs, rl, rq)) return false;
-  int32_t mr = mrel, mq = 0, nxt = 0x7fffffff;
-  bool found = false;
-  ms = 0; ml = 0; mq0 = 0;
-  // the mate's first four ops came in one load (a load per op is a chain of round trips, and the
-  // walk starts over for every piece); longer CIGARs go on from memory
-  bool done = false;
-  auto step = [&](uint32_t cop) {
-    const uint32_t op = cop & 15u;
-    const int32_t len = (int32_t)(cop >> 4);
-    if (op == 0) {
-      if (found) { nxt = mr; done = true; return; }
-      if (mr + len > rs) { found = true; ms = mr; ml = len; mq0 = mq; }
-      mr += len;
-      mq += len;
-    } else {
-      mq += (op == 1 || op == 4) ? len : 0;
-      mr += (op == 2 || op == 3) ? len : 0;
-      if (op > 5) done = true;
-    }
-  };
-  if (mn > 0) step(m4.x);
-  if (!done && mn > 1) step(m4.y);
-  if (!done && mn > 2) step(m4.z);
-  if (!done && mn > 3) step(m4.w);
-  for (uint32_t k = 4; k < mn && !done; k++) step(mcg[k]);
-  const int32_t e = rs + rl, cut = nxt < e ? nxt : e;  // nxt > rs: it lies past an M op that ends after rs
-  sref = rs;
-  slen = cut - rs;
-  sq0 = rq;
-  rq += slen;
-  rs = cut;
-  rl = cut < (int32_t)wlen ? e - cut : 0;
-  return true;
-}
-
 // Block-uniform values that come from global memory arrive through vector loads (the kernel also
 // stores to global memory, so the compiler will not use the scalar cache for them) and would sit
 // in a VGPR of every lane for the whole window: move them to SGPRs - when the window starts, not
@@ -852,13 +518,12 @@ __device__ __forceinline__ Window uni_window(const Window& v) {
 // DEEP = true is the second launch over the extra slices of deep windows: one work item per
 // loop iteration, taken from P.extra_items, flushed with atomic adds on top of the rows the
 // first launch wrote.
-template <bool STITCH, bool CLIP, bool MINQ0, bool DEEP>
+template <bool STITCH, bool MINQ0, bool DEEP>
 __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParams P) {
-  // what a unit brings of the quals: the packer's pass bits (KernelParams.qpass), or nothing (every
-  // base passes)
-  constexpr int QM = MINQ0 ? 0 : 2;
-  constexpr bool EXTRA = STITCH || CLIP;
-  __shared__ BlockSharedT<EXTRA> S;
+  // what a unit brings beside its bases: nothing (every base passes), the packer's pass bits
+  // (KernelParams.qpass), or pass and drop bits (stitch: see stitch_resolve_kernel)
+  constexpr int QM = STITCH ? 3 : MINQ0 ? 0 : 2;
+  __shared__ BlockSharedT<STITCH> S;
   const int tid = threadIdx.x;
   uint32_t n_items = 0;
   if constexpr (DEEP) {
@@ -882,13 +547,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
   }
 
   for (int i = tid; i < kPlanes * kStride / 4; i += kBlock) ((uint4*)S.cnt)[i] = make_uint4(0, 0, 0, 0);
-  if (tid == 0) {
-    S.n_alloc[0] = S.n_alloc[1] = 0;
-    S.more[0] = S.more[1] = 0;
-  }
-  if constexpr (STITCH) {
-    if (tid < 96) S.ex.qthr[tid] = P.qthr[tid] < 96 ? P.qthr[tid] : (uint8_t)96;
-  }
+  if (tid == 0) S.n_alloc[0] = S.n_alloc[1] = 0;
   uint32_t par = 0;  // round parity (block-uniform)
   __syncthreads();
 
@@ -912,13 +571,10 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     }
   }
   uint4 pc0 = make_uint4(0, 0, 0, 0), pc1 = pc0;
-  // stitch: the record's entry of the mate table travels with its core
-  [[maybe_unused]] uint4 pme = pc0;
   if (n_r0 + tid < n_r1) {
     const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
     pc0 = cp[0];
     pc1 = cp[1];
-    if constexpr (STITCH) pme = ((const uint4*)P.mate)[n_r0 + tid];
   }
 
   for (uint32_t item = w_first; item < w_last; item += DEEP ? gridDim.x : 1u) {
@@ -939,12 +595,9 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
     // per-thread record cursor
     int32_t rec = r0 + tid;
     bool have = false, keep = false;
-    uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, qdelta = 0, sslot = 0, aux = 0, span = 0;
+    uint32_t c_cur = 0, n_cigar = 0, blob = 0, lseqnc = 0, sslot = 0, aux = 0, span = 0;
     uint32_t cg0 = 0, cg1 = 0, cg2 = 0;
-    uint4 minfo = make_uint4(0, 0, 0, 0);
-    uint32_t mqd = 0;  // mate qdelta << 16
     int32_t rr = 0, qq = 0;
-    int32_t rem_s = 0, rem_l = 0, rem_q = 0;  // stitch: rest of the M op being cut into pieces
     auto flush = [&]() {
 
       // ---- flush: one lane per position; Depth = sum of the 12 planes (pileup.go:518-570);
@@ -1018,8 +671,8 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         }
       }
     };
-    // A record's core (and, stitching, its entry of the mate table) -> the per-thread cursor.
-    auto decode = [&](const uint4 c0, const uint4 c1, [[maybe_unused]] uint4 me) {
+    // A record's core -> the per-thread cursor.
+    auto decode = [&](const uint4 c0, const uint4 c1) {
       const int32_t pos = (int32_t)c0.x;
       const uint32_t flags = c0.y & 0xffffu, mapq = (c0.y >> 16) & 0xffu;
       aux = c0.y >> 24;
@@ -1029,7 +682,6 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       blob = c1.x;
       cg0 = c1.y; cg1 = c1.z; cg2 = c1.w;
       lseqnc = l_seq | (n_cigar << 16);
-      qdelta = c0.w >> 16;
       const int strand = strand_of((aux & AUX_MATE_SAME) != 0, flags);
       // -flag-exclude, -mapq, blank-read filters (pileup.go:691)
       keep = ((uint32_t)P.flag_exclude & flags) == 0 && (int32_t)mapq >= P.mapq && n_cigar != 0;
@@ -1038,67 +690,39 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
       else keep = keep && (strand != 0 || P.ignore_strand);
       keep = keep && pos < g1 && (int64_t)pos + span > (int64_t)g0;
       sslot = P.ignore_strand ? 0u : (uint32_t)(strand - 1) & 1u;
-      minfo = make_uint4(0, 0, 0, 0);
-      mqd = 0;
       if constexpr (STITCH) {
-        // The record's entry of the mate table (MateEntry, pileup_device.h) says everything
-        // phase 1 needs to know of the mate, so the mate's core is never fetched: one load
-        // beside the record's own core instead of two dependent ones behind it.
-        if (keep && (me.x & MATE_HAS)) {
-          const int32_t delta = ((int32_t)(me.x << 15)) >> 15;  // mate start - own start, 17 bits signed
-          const uint32_t second = (me.x & MATE_SECOND) ? 1u : 0u;
-          // the pair is counted on the strand of the read that found its mate
-          // (pileup.go:799-802); for the stored read that is the mate's strand
-          if (!second && !P.ignore_strand) sslot = (me.x & MATE_PAIR_REV) ? 1u : 0u;
-          minfo.x = (uint32_t)(pos + delta - g0);
-          minfo.y = (me.z & 0xffffu) | ((me.x & MATE_SIMPLE) ? 0x10000u : 0u) | (second << 17) | 0x40000u;  // bit 16: one M op
-          minfo.z = me.y;
-          minfo.w = (me.z >> 16) | ((me.w & 0xffffu) << 16);
-          mqd = me.w & 0xffff0000u;
-        }
+        // a pair is counted on the strand of the read that found its mate (pileup.go:799-802);
+        // stitch_resolve_kernel left that strand in the core of the read stored first
+        if ((aux & AUX_PAIR_FIRST) && !P.ignore_strand) sslot = (aux >> 7) & 1u;
       }
       c_cur = 0;
       rr = pos - g0;
       qq = 0;
-      rem_l = 0;
       have = true;
     };
-    // round 0 works on the records fetched a window ahead; the registers they came in are free
-    // from here on (the next window's are fetched in the last round, behind its phase 1)
-    // Two loop shapes.  LATE (the stitched kernels, which live at the register limit): the
-    // records fetched a window ahead are decoded before the loop and the next window's are
-    // fetched in the window's LAST round, so their registers are never live during a phase 1;
-    // the round's first barrier settles "last" through a flag in LDS.  Otherwise: fetched in
-    // round 0 and the end-of-round barrier is the block-wide vote (measured faster there:
-    // 4.35 against 4.55 ms on chr1 30x).
-    constexpr bool LATE = STITCH;
-    [[maybe_unused]] bool first_round = true;
-    if constexpr (LATE) {
-      if (rec < r1) decode(pc0, pc1, pme);
-    }
+    // round 0 works on the records fetched a window ahead; the next window's are fetched in
+    // round 0 too, behind its first barrier, and the end-of-round barrier is the block-wide vote on
+    // "records left"
+    bool first_round = true;
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = nc0;
-    [[maybe_unused]] uint4 nme = nc0;
-    [[maybe_unused]] bool next_issued = false;
+    bool next_issued = false;
     for (;;) {
       // (no barrier here: the slot counter of this round was reset behind the previous
       // round's first barrier, and phase 1 touches nothing the flush still reads)
       BP_STAMP(1);
       // ---- phase 1: thread = record; read-level filters, CIGAR -> M-segments in the window
-      // (Wave priority: the two workgroups of a CU are in different phases most of the time.
-      // The stitched variant's phase 1 is its long serial part - mate lookup, piece walk - and
-      // goes first, 6.02 -> 5.96 ms on chr1 30x; without stitching the unit pass goes first,
-      // 4.32 -> 4.30 ms; the other way round each is slower.)
-      __builtin_amdgcn_s_setprio(STITCH ? 3 : 0);
+      // (Wave priority: the two workgroups of a CU are in different phases most of the time; the
+      // unit pass goes first, 4.32 -> 4.30 ms on chr1 30x.)
+      __builtin_amdgcn_s_setprio(0);
       const bool has_rec = rec < r1;
       if (has_rec && !have) {
-        uint4 c0 = pc0, c1 = pc1, me = pme;
-        if (LATE || !first_round) {
+        uint4 c0 = pc0, c1 = pc1;
+        if (!first_round) {
           const uint4* cp = (const uint4*)(P.cores + rec);
           c0 = cp[0];
           c1 = cp[1];
-          if constexpr (STITCH) me = ((const uint4*)P.mate)[rec];
         }
-        decode(c0, c1, me);
+        decode(c0, c1);
       }
       first_round = false;
       // CIGAR walk (pileup.go:275-363): every M op is one segment; the wave admits up to two
@@ -1109,34 +733,9 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         SegIn A = {0, 0, 0}, B = {0, 0, 0};
         uint32_t cB = 0;              // cursor after the last segment taken
         int32_t rrB = 0, qqB = 0;
-        uint4 miA = minfo, miB = minfo;
-        uint32_t mxA = 0, mxB = 0;  // mate: read index of the M op's first base | qdelta << 16
-        int32_t rsB = 0, rlB = 0, rqB = 0;
-        bool pieces = false;
-        if constexpr (STITCH) pieces = (minfo.y & 0x50000u) == 0x40000u;  // mate with several CIGAR ops
-        mxA = mxB = mqd;
         if (more) {
           const uint32_t* cg = (const uint32_t*)(P.blob + (uint64_t)blob * 8);
-          if (pieces) {
-            const uint32_t* mcg = (const uint32_t*)(P.blob + (uint64_t)minfo.z * 8);
-            const uint32_t mn = minfo.w >> 16;
-            const u32x4a m4 = *(const u32x4a*)mcg;  // (past a short CIGAR this reads into the mate's bases: unused)
-            uint32_t c = c_cur;
-            int32_t r_ = rr, q_ = qq, rs = rem_s, rl = rem_l, rq = rem_q;
-            int32_t sA = 0, lA = 0, qA = 0;
-            int32_t msA = 0, mlA = 0, mqA = 0;
-            // One piece per admission step (the other paths take two M ops): a second walk's
-            // results would have to live next to the first's, and this path is what decides the
-            // stitched variants' register count (with two: 16 VGPRs spilled once the mate's ops
-            // are held in registers).
-            wantA = next_piece(cg, cg0, cg1, cg2, n_cigar, wlen, c, r_, q_, rs, rl, rq, mcg, m4, mn, (int32_t)minfo.x,
-                               sA, lA, qA, msA, mlA, mqA);
-            A.sref = sA; A.len = lA; A.q0 = qA;
-            miA.x = (uint32_t)msA; miA.y = (minfo.y & 0xffff0000u) | (uint32_t)mlA; mxA = mqd | (uint32_t)mqA;
-            cB = c; rrB = r_; qqB = q_;
-            rsB = rs; rlB = rl; rqB = rq;
-            if (!wantA) more = false;
-          } else if (aux & AUX_SIMPLE) {
+          if (aux & AUX_SIMPLE) {
             wantA = true;
             A.sref = rr;
             A.len = (int32_t)span;
@@ -1153,15 +752,11 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           }
         }
         if (!__any(wantA)) break;
-        const bool ok = emit_wave<EXTRA, STITCH, !MINQ0>(S, wantA, A, wantB, B, wlen, blob, lseqnc, qdelta, sslot, rec, par, miA, mxA, miB, mxB);
+        const bool ok = emit_wave<QM, STITCH>(S, wantA, A, wantB, B, wlen, blob, lseqnc, sslot, rec, par);
         if (wantA) {
           if (!ok) {
             failed = true;
             more = false;
-          } else if (pieces) {
-            c_cur = cB; rr = rrB; qq = qqB;
-            rem_s = rsB; rem_l = rlB; rem_q = rqB;
-            more = rem_l != 0 || c_cur < n_cigar;
           } else if (aux & AUX_SIMPLE) {
             more = false;
           } else {
@@ -1174,92 +769,61 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         rec += kBlock;
         have = false;
       }
-      // the barrier between the phases also settles whether this is the window's last round:
-      // a thread with records left says so in the round's flag (everybody stores the same 1)
       const int pending = rec < r1;
-      // LATE: a thread with records left says so in the round's flag (everybody stores the same 1)
-      if constexpr (LATE) {
-        if (pending) S.more[par] = 1u;
-      }
       BP_STAMP(2);
       __syncthreads();
-      bool last = false;
-      if constexpr (LATE) last = S.more[par] == 0u;
       BP_STAMP(3);
 
       // ---- prefetch for the next window: everything it needs from global memory before its
       // unit loads (window descriptor, record range two ahead, this thread's first record core)
-      // is fetched while this window is in phase 2 and flushed.  LATE: behind phase 2, when the
-      // units' registers are free again (issued before it, the compiler parks the 12 dwords in
-      // scratch, and the store has to wait for the load: the whole latency at the head of phase 2)
-      auto prefetch_next = [&]() {
-        if (LATE ? last : !next_issued) {
-          next_issued = true;
-          if constexpr (DEEP) {
-            if (item + gridDim.x < w_last) {
-              const uint4 it = P.extra_items[item + gridDim.x];
-              n_win = P.windows[it.x];
-              n_r0 = (int32_t)it.y;
-              n_r1 = (int32_t)it.z;
-              if constexpr (LATE) {  // (no registers to hold them in until the window starts)
-                n_win = uni_window(n_win);
-                n_r0 = uni(n_r0);
-                n_r1 = uni(n_r1);
-              }
-              if (n_r0 + tid < n_r1) {
-                const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
-                nc0 = cp[0];
-                nc1 = cp[1];
-                if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
-              }
-            }
-          } else if (item + 1 < w_last) {
-            n_r0 = nn_r0;
-            n_r1 = nn_r1;
-            n_win = P.windows[item + 1];
-            if constexpr (LATE) n_win = uni_window(n_win);
+      // is fetched while this window is in phase 2 and flushed.
+      if (!next_issued) {
+        next_issued = true;
+        if constexpr (DEEP) {
+          if (item + gridDim.x < w_last) {
+            const uint4 it = P.extra_items[item + gridDim.x];
+            n_win = P.windows[it.x];
+            n_r0 = (int32_t)it.y;
+            n_r1 = (int32_t)it.z;
             if (n_r0 + tid < n_r1) {
               const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
               nc0 = cp[0];
               nc1 = cp[1];
-              if constexpr (STITCH) nme = ((const uint4*)P.mate)[n_r0 + tid];
-            }
-            if (item + 2 < w_last) {
-              nn_r0 = P.win_r0[item + 2];
-              nn_r1 = P.win_r1[item + 2];
-              if constexpr (LATE) {
-                nn_r0 = uni(nn_r0);
-                nn_r1 = uni(nn_r1);
-              }
             }
           }
+        } else if (item + 1 < w_last) {
+          n_r0 = nn_r0;
+          n_r1 = nn_r1;
+          n_win = P.windows[item + 1];
+          if (n_r0 + tid < n_r1) {
+            const uint4* cp = (const uint4*)(P.cores + n_r0 + tid);
+            nc0 = cp[0];
+            nc1 = cp[1];
+          }
+          if (item + 2 < w_last) {
+            nn_r0 = P.win_r0[item + 2];
+            nn_r1 = P.win_r1[item + 2];
+          }
         }
-      };
-      if constexpr (!LATE) prefetch_next();
+      }
 
       // ---- phase 2: thread = unit (32 window positions of one segment); kDepth units in
       // flight per lane
-      __builtin_amdgcn_s_setprio(STITCH ? 0 : 3);
-      if (tid == 0) {  // next round's counter and flag; next touched after the barrier below
-        S.n_alloc[par ^ 1u] = 0;
-        S.more[par ^ 1u] = 0;
-      }
+      __builtin_amdgcn_s_setprio(3);
+      if (tid == 0) S.n_alloc[par ^ 1u] = 0;  // next round's counter; next touched after the barrier below
       const uint32_t n_alloc_u = (uint32_t)S.n_alloc[par];
-      const uint32_t T = (n_alloc_u & 0xffffu) < (uint32_t)kUnitCap ? (n_alloc_u & 0xffffu) : (uint32_t)kUnitCap;
-      [[maybe_unused]] const uint32_t n_ovl = (n_alloc_u >> 16) < (uint32_t)kUnitCap ? (n_alloc_u >> 16) : (uint32_t)kUnitCap;
+      const uint32_t T = n_alloc_u < (uint32_t)kUnitCap ? n_alloc_u : (uint32_t)kUnitCap;
 #ifdef BP_STAMPS_P2
       const uint32_t wbase = (uint32_t)tid & ~63u;
-#endif
-#ifdef BP_STAMPS_P2
       // diagnostic: serialise one unit at a time and time its three parts
       {
         unsigned long long a_issue = 0, a_wait = 0, a_proc = 0;
         for (uint32_t tb = wbase; tb < T; tb += kBlock) {
-          UnitLoad<QM, false> L1;
+          UnitLoad<QM> L1;
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t0 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          issue_unit<QM, false>(P, S, slot_of(tb + (tid & 63), T, (T + 63) / 64), T, L1);
+          issue_unit<QM, STITCH>(P, S, slot_of(tb + (tid & 63), T, (T + 63) / 64), T, L1);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1268,7 +832,7 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t2 = __builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
-          process_unit_plain<QM>(S, L1, cpo);
+          process_unit_plain<QM>(P, S, L1, cpo);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -1284,82 +848,223 @@ __global__ __launch_bounds__(kBlock, BP_MINWAVES) void pileup_kernel(KernelParam
         // Every thread runs n_it unit slots (block-uniform).  The steady-state loop has no
         // branch in its body, so the compiler's counted vmcnt waits keep kD units' loads in
         // flight; at 30x a window is 2-3 units per thread and the loop body rarely runs.
-        // (stitched with -clip: one unit in flight, the overlap groups' clip masks need the room)
-        // Stitched runs treat a unit in two parts.  Every unit goes through the plain path with
-        // the packer's pass bits, leaving out the positions the record's mate covers too (Depth++
-        // once per pair position, pileup.go:409-430).  The units whose record has to decide such
-        // positions (it found its mate in the table) were listed by phase 1 - few at whole-genome
-        // insert sizes; for them the mate's bases and quals are loaded next to the record's own,
-        // 8 positions to a lane (OvGroup), and just those positions are counted.  That comes
-        // FIRST, its loads issued together with the first plain unit's: the round trip is shared.
-        // So the bulk of the units runs at the plain path's register budget, and the mate's
-        // loads are issued only where they are used.
-        constexpr int kD = STITCH ? (CLIP ? 1 : kDepthQ) : kDepth;
+        constexpr int kD = STITCH ? kDepthQ : kDepth;
         const uint32_t R = (T + 63) / 64;  // rows of the 8 x R slot grid
         const uint32_t n_it = (R * 64 + kBlock - 1) / kBlock;
-        UnitLoad<QM, false> L[kD];
+        UnitLoad<QM> L[kD];
         uint32_t t = (uint32_t)tid;
-        auto issue1 = [&](UnitLoad<QM, false>& U, uint32_t tt) {
-          issue_unit<QM, false>(P, S, slot_of(tt, T, R), T, U);
-          if constexpr (STITCH) {
-            bool second = false;
-            if (U.meta & 0x10000u) U.mask &= ~mate_overlap(S, U.seg, U.meta & 0x3fu, second);
-          }
-        };
-        if constexpr (STITCH) {
-          const uint32_t n_ovl_ = n_ovl;
-          if (n_ovl_ != 0) {  // block-uniform
-            OvGroup G;
-            issue_ov_group(P, S, (uint32_t)tid, n_ovl_, T, cpo, G);
-            issue1(L[0], t);
-            t += kBlock;
-            process_ov_group<CLIP>(P, S, G);
-            for (uint32_t w = (uint32_t)tid + kBlock; w - (uint32_t)tid < 4u * n_ovl_; w += kBlock) {  // deep windows only
-              issue_ov_group(P, S, w, n_ovl_, T, cpo, G);
-              process_ov_group<CLIP>(P, S, G);
-            }
-          } else {
-            issue1(L[0], t);
-            t += kBlock;
-          }
-        } else {
-          issue1(L[0], t);
-          t += kBlock;
-        }
 #pragma unroll
-        for (int d = 1; d < kD; d++) {
-          issue1(L[d], t);
+        for (int d = 0; d < kD; d++) {
+          issue_unit<QM, STITCH>(P, S, slot_of(t, T, R), T, L[d]);
           t += kBlock;
         }
         uint32_t it = 0;
         for (; it + kD < n_it; it += kD) {
 #pragma unroll
           for (int d = 0; d < kD; d++) {
-            process_unit_plain<QM>(S, L[d], cpo);
-            issue1(L[d], t);
+            process_unit_plain<QM>(P, S, L[d], cpo);
+            issue_unit<QM, STITCH>(P, S, slot_of(t, T, R), T, L[d]);
             t += kBlock;
           }
         }
         const uint32_t rem = n_it - it;
 #pragma unroll
         for (int d = 0; d < kD; d++)
-          if ((uint32_t)d < rem) process_unit_plain<QM>(S, L[d], cpo);
+          if ((uint32_t)d < rem) process_unit_plain<QM>(P, S, L[d], cpo);
       }
 #endif
-      if constexpr (LATE) prefetch_next();
       BP_STAMP(4);
       par ^= 1u;
-      if constexpr (LATE) __syncthreads();
-      else last = !__syncthreads_or(pending);
-      if (last) break;
+      if (!__syncthreads_or(pending)) break;
     }
     BP_STAMP(5);
     flush();
     BP_STAMP(6);
     pc0 = nc0;
     pc1 = nc1;
-    if constexpr (STITCH) pme = nme;
   }
+}
+
+// ---- stitching: the pair rule, worked out once per job (addReadPair, pileup.go:406-446)
+// A record without a mate in the table does nothing.  The read of a pair that was stored first
+// gets the pair's strand into its core (the pair is counted on the strand of the read that found
+// its mate, pileup.go:799-802).  For the read that found its mate both CIGARs are walked side by
+// side and, for every reference position that an M op of each read covers:
+//   * the mate's drop bit is set there and its pass bit cleared (the position is counted once, here);
+//   * the reads disagree: the read's own base becomes N (code 15 -> X, counted whatever the quality);
+//   * they agree: its own pass bit becomes qualPassTable.lookup2(q0, q1) on the clipped quals
+//     (qthr[q] = smallest mate quality that passes beside q, qual.go:35-77); the counting kernel
+//     then counts the base, or depth only, and X regardless, as it does for any base;
+//   * they agree and a quality is >= 96: pass and drop bit both set - the reference panics on
+//     that table lookup; the counting kernel reports the record when a window gets there.
+// Each pair is worked once (AUX_PAIR_REV without AUX_PAIR_FIRST marks a read that has done it):
+// a second pass would see the Ns it wrote.
+// Mapping: thread = record for the table look-up; the reads of a wave's 64 records that have a pair
+// to work are then dealt to its four groups of 16 lanes, lane = 8 consecutive bases of the read (one
+// dword of packed bases, two of quals, one byte of pass bits; the mate's bytes for the same
+// positions realigned in registers) or one dword of the mate's bits.  Pairs of single-M-op reads
+// (nearly all) touch every byte once and use plain stores; with indels two stretches can meet in
+// one dword, and the updates go through L2 atomics.
+__device__ __forceinline__ uint32_t bits_lo_hi(int32_t lo, int32_t hi, int32_t width) {  // bits [lo, hi) of a width-bit word
+  if (lo < 0) lo = 0;
+  if (hi > width) hi = width;
+  if (hi <= lo) return 0u;
+  return (hi - lo >= 32 ? 0xffffffffu : ((1u << (hi - lo)) - 1u)) << lo;
+}
+
+__device__ __forceinline__ void resolve_stretch(const KernelParams& P, const uint8_t* qthr, uint32_t sl, bool plain,
+                                                int32_t bi0, int32_t mi0, int32_t len, uint32_t ol, uint32_t ml,
+                                                uint32_t* oseq, uint32_t* obits, const uint32_t* oq,
+                                                const uint32_t* mseq, uint32_t* mbits, const uint32_t* mq) {
+  // (a CIGAR longer than its read: nothing to look at past the read's end)
+  if (len > (int32_t)ol - bi0) len = (int32_t)ol - bi0;
+  if (len > (int32_t)ml - mi0) len = (int32_t)ml - mi0;
+  if (len <= 0) return;
+  const int32_t clip = P.clip;
+  const uint32_t g1 = (uint32_t)(bi0 + len - 1) >> 3;
+  for (uint32_t g = ((uint32_t)bi0 >> 3) + sl; g <= g1; g += 16) {
+    const int32_t b8 = (int32_t)(8u * g);  // read index of the group's first base
+    const uint32_t v8 = bits_lo_hi(bi0 - b8, bi0 + len - b8, 8);
+    const uint32_t sw = oseq[g];
+    const int32_t m0 = mi0 + (b8 - bi0);   // the mate's read index there (>= -7: the loads below may start
+                                           // a few bytes before the mate's bases / quals, inside the buffer)
+    const uint32_t* const mp = mseq + (m0 >> 3);
+    const uint32_t msw = __builtin_amdgcn_alignbit(mp[1], mp[0], 4u * ((uint32_t)m0 & 7u));
+    const uint32_t qlo = oq[2 * g], qhi = oq[2 * g + 1];
+    const uint32_t* const mqp = mq + (m0 >> 2);
+    const uint32_t n0 = mqp[0], n1 = mqp[1], n2 = mqp[2];
+    const uint32_t mqlo = __builtin_amdgcn_alignbyte(n1, n0, (uint32_t)m0 & 3u);
+    const uint32_t mqhi = __builtin_amdgcn_alignbyte(n2, n1, (uint32_t)m0 & 3u);
+    // bit k: the reads agree at base k of the group
+    const uint32_t dn = msw ^ sw;
+    uint32_t eq8 = ~(dn | (dn >> 1) | (dn >> 2) | (dn >> 3)) & 0x11111111u;
+    eq8 = (eq8 | (eq8 >> 3)) & 0x03030303u;
+    eq8 = (eq8 | (eq8 >> 6)) & 0x000f000fu;
+    eq8 = (eq8 | (eq8 >> 12)) & 0xffu;
+    const uint32_t x8 = v8 & ~eq8, e8 = v8 & eq8;
+    uint32_t set8 = 0, bad8 = 0;
+    for (int k = 0; k < 8; k++) {
+      if (!((e8 >> k) & 1u)) continue;
+      const uint32_t q0 = clipped_qual(((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu, b8 + k, (int32_t)ol, clip);
+      const uint32_t q1 = clipped_qual(((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu, m0 + k, (int32_t)ml, clip);
+      if (q0 >= 96u || q1 >= 96u) bad8 |= 1u << k;
+      else if (q1 >= (uint32_t)qthr[q0]) set8 |= 1u << k;
+    }
+    set8 |= bad8;
+    const uint32_t clr8 = e8 & ~set8;
+    if (x8) {
+      uint32_t m = (x8 | (x8 << 12)) & 0x000f000fu;
+      m = (m | (m << 6)) & 0x03030303u;
+      m = (m | (m << 3)) & 0x11111111u;
+      m = (m << 4) - m;
+      if (plain) oseq[g] = sw | m; else atomicOr(&oseq[g], m);
+    }
+    uint32_t* const pw = obits + 2 * (size_t)(g >> 2);
+    if (plain) {
+      uint8_t* const pb = (uint8_t*)pw + (g & 3u);
+      if (e8) *pb = (uint8_t)((*pb & ~clr8) | set8);
+      if (bad8) pb[4] = (uint8_t)(pb[4] | bad8);
+    } else {
+      const uint32_t sh = 8u * (g & 3u);
+      if (clr8) atomicAnd(&pw[0], ~(clr8 << sh));
+      if (set8) atomicOr(&pw[0], set8 << sh);
+      if (bad8) atomicOr(&pw[1], bad8 << sh);
+    }
+  }
+  const uint32_t w1 = (uint32_t)(mi0 + len - 1) >> 5;
+  for (uint32_t w = ((uint32_t)mi0 >> 5) + sl; w <= w1; w += 16) {
+    const uint32_t m = bits_lo_hi(mi0 - (int32_t)(32u * w), mi0 + len - (int32_t)(32u * w), 32);
+    if (plain) {
+      mbits[2 * (size_t)w] &= ~m;
+      mbits[2 * (size_t)w + 1] |= m;
+    } else {
+      atomicAnd(&mbits[2 * (size_t)w], ~m);
+      atomicOr(&mbits[2 * (size_t)w + 1], m);
+    }
+  }
+}
+
+// next M op of a CIGAR: [s, e) on the reference (relative to the deciding read's start), first read index q0
+struct MOpCursor {
+  const uint32_t* cg;
+  uint32_t n, k;
+  int32_t r, q, s, e, q0;
+  __device__ __forceinline__ bool next() {
+    while (k < n) {
+      const uint32_t cop = cg[k++];
+      const uint32_t op = cop & 15u;
+      const int32_t len = (int32_t)(cop >> 4);
+      if (op == 0) {
+        s = r; e = r + len; q0 = q;
+        r += len; q += len;
+        return true;
+      }
+      q += (op == 1 || op == 4) ? len : 0;
+      r += (op == 2 || op == 3) ? len : 0;
+      if (op > 5) k = n;  // (the host rejected reachable bad ops, pileup.go:355-359)
+    }
+    return false;
+  }
+};
+
+__global__ __launch_bounds__(256) void stitch_resolve_kernel(KernelParams P, int64_t n) {
+  __shared__ uint8_t s_qthr[96];
+  __shared__ uint8_t s_slot[4][64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  if (tid < 96) s_qthr[tid] = P.qthr[tid];
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  bool work = false;
+  if (i < n) {
+    const uint32_t mx = P.mate[i].x;
+    if (mx & MATE_HAS) {
+      uint8_t* const aux_p = (uint8_t*)(P.cores + i) + 7;  // ReadCore::aux
+      const uint32_t aux = *aux_p;
+      if (!(mx & MATE_SECOND)) {
+        *aux_p = (uint8_t)(aux | AUX_PAIR_FIRST | ((mx & MATE_PAIR_REV) ? AUX_PAIR_REV : 0));
+      } else if ((aux & (AUX_PAIR_FIRST | AUX_PAIR_REV)) != AUX_PAIR_REV) {  // not done in an earlier pass
+        *aux_p = (uint8_t)(aux | AUX_PAIR_REV);
+        work = true;
+      }
+    }
+  }
+  const unsigned long long todo = __ballot(work);
+  if (work) s_slot[wv][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (uint8_t)lane;
+  __syncthreads();
+  const uint32_t n_todo = (uint32_t)__popcll(todo);
+  const uint32_t sub = lane >> 4, sl = lane & 15u;
+  uint8_t* const blob = (uint8_t*)P.blob;
+  for (uint32_t k = sub; k < n_todo; k += 4) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + wv * 64 + s_slot[wv][k];
+    const uint4 me = ((const uint4*)P.mate)[r];
+    const uint4 c0 = ((const uint4*)(P.cores + r))[0];
+    const uint32_t on = c0.z & 0xffffu, ol = c0.w & 0xffffu, oqd = c0.w >> 16;
+    const uint32_t mn = me.w & 0xffffu, mqd = me.w >> 16, ml = me.z >> 16;
+    if (ol == 0xffffu || ml == 0xffffu) continue;  // (no payload kept: such a read passes no max-read-len)
+    uint8_t* const ob = blob + (uint64_t)((const uint32_t*)(P.cores + r))[4] * 8;
+    uint8_t* const mb = blob + (uint64_t)me.y * 8;
+    uint32_t* const oseq = (uint32_t*)(ob + ((on + 1) & ~1u) * 4);
+    uint32_t* const mseq = (uint32_t*)(mb + ((mn + 1) & ~1u) * 4);
+    uint32_t* const obits = oseq + ((ol + 7) >> 3);
+    uint32_t* const mbits = mseq + ((ml + 7) >> 3);
+    const uint32_t* const oq = (const uint32_t*)(ob + 8 * (size_t)oqd);
+    const uint32_t* const mq = (const uint32_t*)(mb + 8 * (size_t)mqd);
+    const bool plain = ((c0.y >> 24) & AUX_SIMPLE) && (me.x & MATE_SIMPLE);
+    MOpCursor A{(const uint32_t*)ob, on, 0, 0, 0, 0, 0, 0};
+    MOpCursor B{(const uint32_t*)mb, mn, 0, ((int32_t)(me.x << 15)) >> 15, 0, 0, 0, 0};  // mate start - own start, 17 bits signed
+    bool ha = A.next(), hb = B.next();
+    while (ha && hb) {
+      const int32_t lo = A.s > B.s ? A.s : B.s, hi = A.e < B.e ? A.e : B.e;
+      if (hi > lo)
+        resolve_stretch(P, s_qthr, sl, plain, A.q0 + (lo - A.s), B.q0 + (lo - B.s), hi - lo, ol, ml, oseq, obits, oq, mseq,
+                        mbits, mq);
+      if (A.e <= B.e) ha = A.next(); else hb = B.next();
+    }
+  }
+}
+
+void launch_stitch_resolve(const KernelParams& P, hipStream_t s) {
+  if (P.n_reads <= 0 || !P.mate) return;
+  hipLaunchKernelGGL(stitch_resolve_kernel, dim3((unsigned)((P.n_reads + 255) / 256)), dim3(256), 0, s, P, P.n_reads);
 }
 
 __global__ void column_sums_kernel(const uint32_t* rows, int64_t n_rows, unsigned long long* sums) {
@@ -2081,16 +1786,15 @@ void launch_plan(const KernelParams& P, int32_t* r0, int32_t* r1, hipStream_t s)
 template <bool DEEP>
 static void launch_pileup_variant(const KernelParams& P, dim3 g, hipStream_t s) {
   const dim3 b(kBlock);
-  const bool clip = P.clip > 0;
   if (P.stitch) {
-    if (clip) hipLaunchKernelGGL((pileup_kernel<true, true, false, DEEP>), g, b, 0, s, P);
-    else hipLaunchKernelGGL((pileup_kernel<true, false, false, DEEP>), g, b, 0, s, P);
+    // pair rule, quality rule and clip are in the payloads' pass and drop bits (stitch_resolve_kernel)
+    hipLaunchKernelGGL((pileup_kernel<true, false, DEEP>), g, b, 0, s, P);
   } else if (P.min_base_qual == 0) {
     // every base passes the quality rule, clipped or not: the quals are never read
-    hipLaunchKernelGGL((pileup_kernel<false, false, true, DEEP>), g, b, 0, s, P);
+    hipLaunchKernelGGL((pileup_kernel<false, true, DEEP>), g, b, 0, s, P);
   } else {
     // quality rule and clip are in the packer's pass bits: one variant
-    hipLaunchKernelGGL((pileup_kernel<false, false, false, DEEP>), g, b, 0, s, P);
+    hipLaunchKernelGGL((pileup_kernel<false, false, DEEP>), g, b, 0, s, P);
   }
 }
 

@@ -108,6 +108,10 @@ typedef struct bp_timing {
    * threads (spans, filters, name hashes, packing into the pinned staging buffers) */
   float submit_scan_ms;
   float submit_pack_ms;
+  /* stitch mode: the kernel that works out the pair rule (addReadPair, pileup.go:406-446) for every
+   * pair of the job and leaves the outcome in the packed records, summed over the computes that
+   * ran it (normally the first one after the last submit; 0 otherwise) */
+  float stitch_resolve_ms;
 } bp_timing;
 
 /* Library/runtime probe.  Fails (BP_EDEVICE) when no HIP device is usable: there is no

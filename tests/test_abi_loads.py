@@ -32,7 +32,7 @@ def test_struct_sizes_match_header():
     # bp_opts: 16 int32; bp_record_batch: int64 + 16 pointers; bp_timing: 3 float + pad + 2 int64
     assert C.sizeof(_abi.bp_opts) == 64
     assert C.sizeof(_abi.bp_record_batch) == 8 + 16 * 8
-    assert C.sizeof(_abi.bp_timing) == 48
+    assert C.sizeof(_abi.bp_timing) == 56
 
 
 def test_no_cpu_fallback_without_device():

@@ -1672,6 +1672,13 @@ int bp_compute(bp_handle* h) {
   if (need_resolve) {
     // the pair rule, once for the pairs the table has gained (each pair is worked once: the
     // kernel marks the reads it has done); the counting kernels then find its outcome in the payloads
+    {
+      // (an empty launch first: the first launch of a kernel has the runtime load its code, and that
+      // host time would otherwise sit between the two events)
+      KernelParams P0 = P;
+      P0.n_reads = 0;
+      launch_stitch_resolve(P0, h->stream);
+    }
     HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
     launch_stitch_resolve(P, h->stream);
     HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));

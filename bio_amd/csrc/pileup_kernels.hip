@@ -912,6 +912,29 @@ __device__ __forceinline__ uint32_t bits_lo_hi(int32_t lo, int32_t hi, int32_t w
   return (hi - lo >= 32 ? 0xffffffffu : ((1u << (hi - lo)) - 1u)) << lo;
 }
 
+// byte-wise a >= b (flag in bit 7 of each byte) for bytes a < 128, any b
+__device__ __forceinline__ uint32_t ge_bytes(uint32_t a, uint32_t b) {
+  constexpr uint32_t H = 0x80808080u;
+  // b >= 128 can never be reached; else (a | 0x80) - b keeps bit 7 iff a >= b
+  return ((a | H) - (b & 0x7f7f7f7fu)) & ~b & H;
+}
+
+// bytes of q at clipped read positions -> 2 (clipQuals, pileup_support.go:51-69); the group's 8
+// bases are read indices b8 .. b8+7 of a read of l bases
+__device__ __forceinline__ void clip8(uint32_t& qlo, uint32_t& qhi, int32_t b8, int32_t l, int32_t clip) {
+  uint32_t cm;  // bit k: base b8 + k is clipped
+  if (2 * clip >= l) cm = 0xffu;
+  else cm = (bits_lo_hi(0, clip - b8, 8) | bits_lo_hi(l - clip - b8, 8, 8)) & 0xffu;
+  if (!cm) return;
+  const uint32_t lo = ((cm & 15u) * 0x00204081u & 0x01010101u) * 0xffu, hi = ((cm >> 4) * 0x00204081u & 0x01010101u) * 0xffu;
+  qlo = (qlo & ~lo) | (0x02020202u & lo);
+  qhi = (qhi & ~hi) | (0x02020202u & hi);
+}
+
+// One stretch of reference positions that an M op of each read covers: `len` positions from read
+// index bi0 of the deciding read and mi0 of its mate.  Lane sl of the pair's 16 takes the 8-base
+// groups g0 + sl, g0 + sl + 16, ... of the read and the bit dwords w0 + sl, ... of the mate; every
+// load of a pass is issued before anything is stored.
 __device__ __forceinline__ void resolve_stretch(const KernelParams& P, const uint8_t* qthr, uint32_t sl, bool plain,
                                                 int32_t bi0, int32_t mi0, int32_t len, uint32_t ol, uint32_t ml,
                                                 uint32_t* oseq, uint32_t* obits, const uint32_t* oq,
@@ -921,65 +944,88 @@ __device__ __forceinline__ void resolve_stretch(const KernelParams& P, const uin
   if (len > (int32_t)ml - mi0) len = (int32_t)ml - mi0;
   if (len <= 0) return;
   const int32_t clip = P.clip;
-  const uint32_t g1 = (uint32_t)(bi0 + len - 1) >> 3;
-  for (uint32_t g = ((uint32_t)bi0 >> 3) + sl; g <= g1; g += 16) {
-    const int32_t b8 = (int32_t)(8u * g);  // read index of the group's first base
-    const uint32_t v8 = bits_lo_hi(bi0 - b8, bi0 + len - b8, 8);
-    const uint32_t sw = oseq[g];
-    const int32_t m0 = mi0 + (b8 - bi0);   // the mate's read index there (>= -7: the loads below may start
-                                           // a few bytes before the mate's bases / quals, inside the buffer)
+  constexpr uint32_t H = 0x80808080u;
+  const uint32_t g1 = (uint32_t)(bi0 + len - 1) >> 3, w1 = (uint32_t)(mi0 + len - 1) >> 5;
+  uint32_t g = ((uint32_t)bi0 >> 3) + sl, w = ((uint32_t)mi0 >> 5) + sl;
+  for (; g <= g1 || w <= w1; g += 16, w += 16) {
+    const bool has_g = g <= g1, has_w = w <= w1;
+    const uint32_t gg = has_g ? g : (uint32_t)bi0 >> 3;  // (an idle lane loads what its neighbour loads)
+    const int32_t b8 = (int32_t)(8u * gg);  // read index of the group's first base
+    const int32_t m0 = mi0 + (b8 - bi0);    // the mate's read index there (>= -7: the loads below may start
+                                            // a few bytes before the mate's bases / quals, inside the buffer)
     const uint32_t* const mp = mseq + (m0 >> 3);
-    const uint32_t msw = __builtin_amdgcn_alignbit(mp[1], mp[0], 4u * ((uint32_t)m0 & 7u));
-    const uint32_t qlo = oq[2 * g], qhi = oq[2 * g + 1];
     const uint32_t* const mqp = mq + (m0 >> 2);
+    uint32_t* const pw = obits + 2 * (size_t)(gg >> 2);
+    uint8_t* const pb = (uint8_t*)pw + (gg & 3u);
+    uint32_t* const mw = mbits + 2 * (size_t)(has_w ? w : (uint32_t)mi0 >> 5);
+    const uint32_t sw = oseq[gg];
+    const uint32_t mp0 = mp[0], mp1 = mp[1];
+    const uint32_t qlo_ = oq[2 * gg], qhi_ = oq[2 * gg + 1];
     const uint32_t n0 = mqp[0], n1 = mqp[1], n2 = mqp[2];
-    const uint32_t mqlo = __builtin_amdgcn_alignbyte(n1, n0, (uint32_t)m0 & 3u);
-    const uint32_t mqhi = __builtin_amdgcn_alignbyte(n2, n1, (uint32_t)m0 & 3u);
-    // bit k: the reads agree at base k of the group
-    const uint32_t dn = msw ^ sw;
-    uint32_t eq8 = ~(dn | (dn >> 1) | (dn >> 2) | (dn >> 3)) & 0x11111111u;
-    eq8 = (eq8 | (eq8 >> 3)) & 0x03030303u;
-    eq8 = (eq8 | (eq8 >> 6)) & 0x000f000fu;
-    eq8 = (eq8 | (eq8 >> 12)) & 0xffu;
-    const uint32_t x8 = v8 & ~eq8, e8 = v8 & eq8;
-    uint32_t set8 = 0, bad8 = 0;
-    for (int k = 0; k < 8; k++) {
-      if (!((e8 >> k) & 1u)) continue;
-      const uint32_t q0 = clipped_qual(((k < 4 ? qlo : qhi) >> (8 * (k & 3))) & 0xffu, b8 + k, (int32_t)ol, clip);
-      const uint32_t q1 = clipped_qual(((k < 4 ? mqlo : mqhi) >> (8 * (k & 3))) & 0xffu, m0 + k, (int32_t)ml, clip);
-      if (q0 >= 96u || q1 >= 96u) bad8 |= 1u << k;
-      else if (q1 >= (uint32_t)qthr[q0]) set8 |= 1u << k;
-    }
-    set8 |= bad8;
-    const uint32_t clr8 = e8 & ~set8;
-    if (x8) {
-      uint32_t m = (x8 | (x8 << 12)) & 0x000f000fu;
-      m = (m | (m << 6)) & 0x03030303u;
-      m = (m | (m << 3)) & 0x11111111u;
-      m = (m << 4) - m;
-      if (plain) oseq[g] = sw | m; else atomicOr(&oseq[g], m);
-    }
-    uint32_t* const pw = obits + 2 * (size_t)(g >> 2);
+    uint32_t pold = 0, mpass = 0, mdrop = 0;
     if (plain) {
-      uint8_t* const pb = (uint8_t*)pw + (g & 3u);
-      if (e8) *pb = (uint8_t)((*pb & ~clr8) | set8);
-      if (bad8) pb[4] = (uint8_t)(pb[4] | bad8);
-    } else {
-      const uint32_t sh = 8u * (g & 3u);
-      if (clr8) atomicAnd(&pw[0], ~(clr8 << sh));
-      if (set8) atomicOr(&pw[0], set8 << sh);
-      if (bad8) atomicOr(&pw[1], bad8 << sh);
+      pold = *pb;
+      mpass = mw[0];
+      mdrop = mw[1];
     }
-  }
-  const uint32_t w1 = (uint32_t)(mi0 + len - 1) >> 5;
-  for (uint32_t w = ((uint32_t)mi0 >> 5) + sl; w <= w1; w += 16) {
-    const uint32_t m = bits_lo_hi(mi0 - (int32_t)(32u * w), mi0 + len - (int32_t)(32u * w), 32);
-    if (plain) {
-      mbits[2 * (size_t)w] &= ~m;
-      mbits[2 * (size_t)w + 1] |= m;
-    } else {
-      atomicAnd(&mbits[2 * (size_t)w], ~m);
-      atomicOr(&mbits[2 * (size_t)w + 1], m);
+    if (has_g) {
+      const uint32_t v8 = bits_lo_hi(bi0 - b8, bi0 + len - b8, 8);
+      const uint32_t msw = __builtin_amdgcn_alignbit(mp1, mp0, 4u * ((uint32_t)m0 & 7u));
+      uint32_t qlo = qlo_, qhi = qhi_;
+      uint32_t mqlo = __builtin_amdgcn_alignbyte(n1, n0, (uint32_t)m0 & 3u);
+      uint32_t mqhi = __builtin_amdgcn_alignbyte(n2, n1, (uint32_t)m0 & 3u);
+      if (clip > 0) {
+        clip8(qlo, qhi, b8, (int32_t)ol, clip);
+        clip8(mqlo, mqhi, m0, (int32_t)ml, clip);
+      }
+      // bit k: the reads agree at base k of the group
+      const uint32_t dn = msw ^ sw;
+      uint32_t eq8 = ~(dn | (dn >> 1) | (dn >> 2) | (dn >> 3)) & 0x11111111u;
+      eq8 = (eq8 | (eq8 >> 3)) & 0x03030303u;
+      eq8 = (eq8 | (eq8 >> 6)) & 0x000f000fu;
+      eq8 = (eq8 | (eq8 >> 12)) & 0xffu;
+      const uint32_t x8 = v8 & ~eq8, e8 = v8 & eq8;
+      // bytes >= 96 (in either read): the reference's table lookup is out of range there
+      const uint32_t blo = ((((qlo & 0x7f7f7f7fu) + 0x20202020u) | qlo) | (((mqlo & 0x7f7f7f7fu) + 0x20202020u) | mqlo)) & H;
+      const uint32_t bhi = ((((qhi & 0x7f7f7f7fu) + 0x20202020u) | qhi) | (((mqhi & 0x7f7f7f7fu) + 0x20202020u) | mqhi)) & H;
+      const uint32_t bad8 = (((((blo >> 7) * 0x00204081u) >> 21) & 15u) | (((((bhi >> 7) * 0x00204081u) >> 21) & 15u) << 4)) & e8;
+      // the pair passes iff mate qual >= qthr[own qual] (qualSumTable row, qual.go:35-77): 8 byte
+      // lookups (indices clamped below 96: those positions are `bad` anyway), then a SWAR byte compare
+      const uint32_t ilo = qlo & ~((blo >> 7) * 0xffu) & 0x7f7f7f7fu, ihi = qhi & ~((bhi >> 7) * 0xffu) & 0x7f7f7f7fu;
+      const uint32_t tlo = (uint32_t)qthr[ilo & 0xffu] | ((uint32_t)qthr[(ilo >> 8) & 0xffu] << 8) |
+                           ((uint32_t)qthr[(ilo >> 16) & 0xffu] << 16) | ((uint32_t)qthr[ilo >> 24] << 24);
+      const uint32_t thi = (uint32_t)qthr[ihi & 0xffu] | ((uint32_t)qthr[(ihi >> 8) & 0xffu] << 8) |
+                           ((uint32_t)qthr[(ihi >> 16) & 0xffu] << 16) | ((uint32_t)qthr[ihi >> 24] << 24);
+      // byte-wise mq >= t for mq < 128 (a bad byte's result is overridden), t <= 255: 9-bit compare in two halves
+      const uint32_t plo = ge_bytes(mqlo, tlo), phi = ge_bytes(mqhi, thi);
+      const uint32_t pass8 = ((((plo >> 7) * 0x00204081u) >> 21) & 15u) | (((((phi >> 7) * 0x00204081u) >> 21) & 15u) << 4);
+      const uint32_t set8 = e8 & (pass8 | bad8), clr8 = e8 & ~set8;
+      if (x8) {
+        uint32_t m = (x8 | (x8 << 12)) & 0x000f000fu;
+        m = (m | (m << 6)) & 0x03030303u;
+        m = (m | (m << 3)) & 0x11111111u;
+        m = (m << 4) - m;
+        if (plain) oseq[g] = sw | m; else atomicOr(&oseq[g], m);
+      }
+      if (plain) {
+        if (e8) *pb = (uint8_t)((pold & ~clr8) | set8);
+        if (bad8) pb[4] = (uint8_t)(pb[4] | bad8);
+      } else {
+        const uint32_t sh = 8u * (g & 3u);
+        if (clr8) atomicAnd(&pw[0], ~(clr8 << sh));
+        if (set8) atomicOr(&pw[0], set8 << sh);
+        if (bad8) atomicOr(&pw[1], bad8 << sh);
+      }
+    }
+    if (has_w) {
+      const uint32_t m = bits_lo_hi(mi0 - (int32_t)(32u * w), mi0 + len - (int32_t)(32u * w), 32);
+      if (plain) {
+        mw[0] = mpass & ~m;
+        mw[1] = mdrop | m;
+      } else {
+        atomicAnd(&mw[0], ~m);
+        atomicOr(&mw[1], m);
+      }
     }
   }
 }
@@ -1009,53 +1055,77 @@ struct MOpCursor {
 
 __global__ __launch_bounds__(256) void stitch_resolve_kernel(KernelParams P, int64_t n) {
   __shared__ uint8_t s_qthr[96];
-  __shared__ uint8_t s_slot[4][64];
+  // what the 16 lanes working a pair need of it, left by the lane that looked the record up:
+  // mate entry x, y, z, w | core flags/aux, n_cigar/span, l_seq/qdelta, blob
+  __shared__ uint4 s_pair[4][64][2];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   if (tid < 96) s_qthr[tid] = P.qthr[tid];
   const int64_t i = (int64_t)blockIdx.x * 256 + tid;
   bool work = false;
+  uint4 me = make_uint4(0, 0, 0, 0), c0 = me;
+  uint32_t oblob = 0;
   if (i < n) {
-    const uint32_t mx = P.mate[i].x;
-    if (mx & MATE_HAS) {
+    me = ((const uint4*)P.mate)[i];
+    c0 = ((const uint4*)(P.cores + i))[0];
+    oblob = ((const uint32_t*)(P.cores + i))[4];
+    if (me.x & MATE_HAS) {
       uint8_t* const aux_p = (uint8_t*)(P.cores + i) + 7;  // ReadCore::aux
-      const uint32_t aux = *aux_p;
-      if (!(mx & MATE_SECOND)) {
-        *aux_p = (uint8_t)(aux | AUX_PAIR_FIRST | ((mx & MATE_PAIR_REV) ? AUX_PAIR_REV : 0));
+      const uint32_t aux = c0.y >> 24;
+      if (!(me.x & MATE_SECOND)) {
+        // (proper pairs have both reads on one strand by pileup.GetStrand: the core is written only
+        // where the pair's strand is not the read's own)
+        const uint32_t own_rev = (((aux >> AUX_STRAND_SHIFT) & 3u) - 1u) & 1u, pair_rev = (me.x & MATE_PAIR_REV) ? 1u : 0u;
+        if (own_rev != pair_rev && !(aux & AUX_PAIR_FIRST))
+          *aux_p = (uint8_t)(aux | AUX_PAIR_FIRST | (pair_rev ? AUX_PAIR_REV : 0));
       } else if ((aux & (AUX_PAIR_FIRST | AUX_PAIR_REV)) != AUX_PAIR_REV) {  // not done in an earlier pass
-        *aux_p = (uint8_t)(aux | AUX_PAIR_REV);
-        work = true;
+        // the mate starts `delta` after this read and spans me.z & 0xffff: can they share a position at all?
+        const int32_t delta = ((int32_t)(me.x << 15)) >> 15, ospan = (int32_t)(c0.z >> 16), mspan = (int32_t)(me.z & 0xffffu);
+        // (spans are clamped to 0xffff in the core and the table: such a read may reach further)
+        if ((delta < ospan || ospan == 0xffff) && (delta + mspan > 0 || mspan == 0xffff)) {
+          *aux_p = (uint8_t)(aux | AUX_PAIR_REV);
+          work = true;
+        }
       }
     }
   }
   const unsigned long long todo = __ballot(work);
-  if (work) s_slot[wv][__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u))] = (uint8_t)lane;
+  if (work) {
+    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+    s_pair[wv][slot][0] = me;
+    s_pair[wv][slot][1] = make_uint4(c0.y, c0.z, c0.w, oblob);
+  }
   __syncthreads();
   const uint32_t n_todo = (uint32_t)__popcll(todo);
   const uint32_t sub = lane >> 4, sl = lane & 15u;
   uint8_t* const blob = (uint8_t*)P.blob;
   for (uint32_t k = sub; k < n_todo; k += 4) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + wv * 64 + s_slot[wv][k];
-    const uint4 me = ((const uint4*)P.mate)[r];
-    const uint4 c0 = ((const uint4*)(P.cores + r))[0];
-    const uint32_t on = c0.z & 0xffffu, ol = c0.w & 0xffffu, oqd = c0.w >> 16;
-    const uint32_t mn = me.w & 0xffffu, mqd = me.w >> 16, ml = me.z >> 16;
+    const uint4 m4 = s_pair[wv][k][0], c4 = s_pair[wv][k][1];
+    const uint32_t on = c4.y & 0xffffu, ol = c4.z & 0xffffu, oqd = c4.z >> 16;
+    const uint32_t mn = m4.w & 0xffffu, mqd = m4.w >> 16, ml = m4.z >> 16;
     if (ol == 0xffffu || ml == 0xffffu) continue;  // (no payload kept: such a read passes no max-read-len)
-    uint8_t* const ob = blob + (uint64_t)((const uint32_t*)(P.cores + r))[4] * 8;
-    uint8_t* const mb = blob + (uint64_t)me.y * 8;
+    uint8_t* const ob = blob + (uint64_t)c4.w * 8;
+    uint8_t* const mb = blob + (uint64_t)m4.y * 8;
     uint32_t* const oseq = (uint32_t*)(ob + ((on + 1) & ~1u) * 4);
     uint32_t* const mseq = (uint32_t*)(mb + ((mn + 1) & ~1u) * 4);
     uint32_t* const obits = oseq + ((ol + 7) >> 3);
     uint32_t* const mbits = mseq + ((ml + 7) >> 3);
     const uint32_t* const oq = (const uint32_t*)(ob + 8 * (size_t)oqd);
     const uint32_t* const mq = (const uint32_t*)(mb + 8 * (size_t)mqd);
-    const bool plain = ((c0.y >> 24) & AUX_SIMPLE) && (me.x & MATE_SIMPLE);
+    const int32_t delta = ((int32_t)(m4.x << 15)) >> 15;  // mate start - own start, 17 bits signed
+    if (((c4.x >> 24) & AUX_SIMPLE) && (m4.x & MATE_SIMPLE)) {
+      // one M op each: one stretch, no CIGAR to fetch, every byte touched once
+      const int32_t ospan = (int32_t)(c4.y >> 16), mspan = (int32_t)(m4.z & 0xffffu);
+      const int32_t lo = delta > 0 ? delta : 0, hi = ospan < delta + mspan ? ospan : delta + mspan;
+      if (hi > lo) resolve_stretch(P, s_qthr, sl, true, lo, lo - delta, hi - lo, ol, ml, oseq, obits, oq, mseq, mbits, mq);
+      continue;
+    }
     MOpCursor A{(const uint32_t*)ob, on, 0, 0, 0, 0, 0, 0};
-    MOpCursor B{(const uint32_t*)mb, mn, 0, ((int32_t)(me.x << 15)) >> 15, 0, 0, 0, 0};  // mate start - own start, 17 bits signed
+    MOpCursor B{(const uint32_t*)mb, mn, 0, delta, 0, 0, 0, 0};
     bool ha = A.next(), hb = B.next();
     while (ha && hb) {
       const int32_t lo = A.s > B.s ? A.s : B.s, hi = A.e < B.e ? A.e : B.e;
       if (hi > lo)
-        resolve_stretch(P, s_qthr, sl, plain, A.q0 + (lo - A.s), B.q0 + (lo - B.s), hi - lo, ol, ml, oseq, obits, oq, mseq,
+        resolve_stretch(P, s_qthr, sl, false, A.q0 + (lo - A.s), B.q0 + (lo - B.s), hi - lo, ol, ml, oseq, obits, oq, mseq,
                         mbits, mq);
       if (A.e <= B.e) ha = A.next(); else hb = B.next();
     }
@@ -1063,8 +1133,9 @@ __global__ __launch_bounds__(256) void stitch_resolve_kernel(KernelParams P, int
 }
 
 void launch_stitch_resolve(const KernelParams& P, hipStream_t s) {
-  if (P.n_reads <= 0 || !P.mate) return;
-  hipLaunchKernelGGL(stitch_resolve_kernel, dim3((unsigned)((P.n_reads + 255) / 256)), dim3(256), 0, s, P, P.n_reads);
+  if (!P.mate) return;
+  // (n_reads 0: one workgroup that finds nothing to do)
+  hipLaunchKernelGGL(stitch_resolve_kernel, dim3((unsigned)std::max<int64_t>(1, (P.n_reads + 255) / 256)), dim3(256), 0, s, P, P.n_reads);
 }
 
 __global__ void column_sums_kernel(const uint32_t* rows, int64_t n_rows, unsigned long long* sums) {

@@ -77,6 +77,32 @@ def test_split_submits_and_empty_inputs():
     assert len(pos) == 0
 
 
+@pytest.mark.parametrize("clip", [0, 3])
+def test_stitched_pairs_completed_across_submits_and_computes(clip):
+    """Stitch mode with a compute after every submit: a read counted alone by one compute is half of
+    a pair by the next (its mate came with a later submit), so the pair rule (stitch_resolve_kernel)
+    runs several times over a growing job, each pair worked once; every compute's rows are the
+    oracle's rows for the records submitted so far, and a compute repeated changes nothing."""
+    sb = synth.generate([(0, 0, 60_000, 40.0)], seed=5, insert_mean=200.0, insert_sd=40.0, insert_min=60,
+                        with_names=True)
+    rb = sb.to_record_batch()
+    ref_len, bed = [61_000], {0: [[100, 30_000], [30_500, 59_000]]}
+    opts = O.make_opts(stitch=1, min_base_qual=20, clip=clip)
+    cuts = [0, rb.n // 5, rb.n // 5 + 1, rb.n // 2, rb.n]
+    with snp.PileupJob(opts, ref_len) as job:
+        job.set_bed(bed)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            job.submit(rb.slice(a, b))
+            job.compute()
+            assert_same(job.rows(), O.pileup(opts, ref_len, bed, rb.slice(0, b), parallelism=1), f"after {b} records")
+            job.compute()
+            assert_same(job.rows(), O.pileup(opts, ref_len, bed, rb.slice(0, b), parallelism=1), f"again after {b} records")
+        job.finish()
+        assert_same(job.rows(), O.pileup(opts, ref_len, bed, rb, parallelism=1), "finished")
+        assert job.timing().stitch_resolve_ms > 0
+    sb.close()
+
+
 def _synth_case(regions, bed, ref_len, opts, region_filter=None, **gen):
     sb = synth.generate(regions, **gen)
     rb = sb.to_record_batch()

@@ -51,3 +51,36 @@ with bgzf.Inflater() as inf:
             wall = time.perf_counter() - t0
             print(f"batch {nb:6d} blocks, to_host={to_host}: inflate kernel {kms:.1f} ms = {total / kms / 1e6:.1f} GB/s, "
                   f"crc kernel {cms:.1f} ms = {total / cms / 1e6:.1f} GB/s, wall {wall:.2f} s = {total / wall / 1e9:.1f} GB/s", flush=True)
+
+    # The stages behind the inflate, one at a time on one stream (so that a kernel trace of this
+    # script shows each kernel running alone): the whole file inflated in one call, records found and
+    # their fields read on the device (bp_bam_scan), packed in place (bp_submit_bam_device).
+    import struct
+    from bio_amd import snp
+    from bio_amd.snp import Opts
+    nb = min(len(blocks), 16384)
+    b = blocks[:nb].copy()
+    part = data[: int(b["in_off"][-1] + b["in_len"][-1])]
+    n_out = int(b["out_off"][-1] + b["out_len"][-1])
+    head = bytearray()
+    for r in b[:4]:
+        head += zlib.decompress(data[r["in_off"]:r["in_off"] + r["in_len"]].tobytes(), -15)
+    l_text = struct.unpack_from("<I", head, 4)[0]
+    q = 12 + l_text
+    for _ in range(struct.unpack_from("<I", head, 8 + l_text)[0]):
+        q += 8 + struct.unpack_from("<I", head, q)[0]
+    inf.inflate(part, b, to_host=False)
+    t0 = time.perf_counter()
+    rc, cols, ex, stopped, cstruct = inf.scan(q, n_out, 1)
+    scan_s = time.perf_counter() - t0
+    n_rec = len(cols["off"])
+    print(f"scan: rc {rc}, {n_rec} records of {ex - q} stream bytes in {scan_s * 1e3:.1f} ms wall (kernels + 13 column copies)", flush=True)
+    for mq in (0, 20):
+        with snp.PileupJob(snp.device_opts(Opts(MinBaseQual=mq)), [L]) as job:
+            job.set_bed({0: [[0, L]]})
+            t0 = time.perf_counter()
+            job.submit_bam_device(inf.device_output, n_out, cstruct, 0, n_rec)
+            sub_s = time.perf_counter() - t0
+            job.finish()
+            print(f"submit_bam_device (min_base_qual {mq}): {n_rec} records, {ex - q} bytes in {sub_s * 1e3:.1f} ms wall "
+                  f"(host scan of the columns + pack kernel); depth sum {job.column_sums()[0]}", flush=True)

@@ -340,16 +340,20 @@ typedef struct bp_bam_columns {
  * device; `first` = the start of a record) for whole records: *n of them, columns filled, *exit
  * = the offset behind the last whole record, *stopped = 1 when a record cut off by `end` (or an
  * invalid block size) follows there.  The chain of block sizes is walked in parallel stretches
- * from guessed starts, every guess verified against the walk before it; returns 1 (nothing
- * filled) when a guess failed and the caller should walk this stream on the host, a negative
- * BP_E* code on errors (BP_ENOMEM: more records than cols->cap). */
+ * from guessed starts, every guess verified in order against the walk before it and a stretch
+ * whose guess was wrong or missing walked again from the right place, so the records found are
+ * those of a serial walk.  Returns 1 (nothing filled) when a stretch holds more records than the
+ * scan has room for (records of a few bytes: not BAM reads) and the caller should walk this
+ * stream on the host, a negative BP_E* code on errors (BP_ENOMEM: more records than cols->cap). */
 int bp_bam_scan(bp_inflater* f, const uint8_t* stream, uint64_t first, uint64_t end, int32_t n_ref,
                 bp_bam_columns* cols, int64_t* n, uint64_t* exit, int32_t* stopped);
 /* bp_submit_bam for records [first_record, first_record + n) of such a scan: `stream` is the
  * DEVICE address of the stream the columns' offsets refer to (on the job's device); nothing of
  * the records is read on the host.  Only for jobs without stitching (the mate table is keyed by
  * read names, which are in the stream) and for records whose facts carry neither bit 1 nor bit 2
- * (the caller hands such records over with bp_submit_bam from a host copy). */
+ * (the caller hands such records over with bp_submit_bam from a host copy).  The pack kernel
+ * loads whole aligned 4-byte words: the word that holds the stream's last byte must be readable
+ * (any hipMalloc'ed buffer is). */
 int bp_submit_bam_device(bp_handle* h, const uint8_t* stream, size_t n_bytes, const bp_bam_columns* cols,
                          int64_t first_record, int64_t n);
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/patch_traffic.py <cfg>...: a bench line taken before its PMC passes cannot know their
-result; fill profiles/r02_bench_<cfg>.json's roofline.traffic from profiles/traffic_<cfg>.json of
+result; fill profiles/r03_bench_<cfg>.json's roofline.traffic from profiles/traffic_<cfg>.json of
 the same session (same kernel sources: the hash is checked)."""
 import json
 import sys
@@ -10,7 +10,7 @@ import bench
 
 h = bench.kernel_source_hash()
 for c in sys.argv[1:]:
-    p = f"profiles/r02_bench_{c}.json"
+    p = f"profiles/r03_bench_{c}.json"
     d = json.load(open(p))
     t = json.load(open(f"profiles/traffic_{c}.json"))
     assert t["kernel_source_sha256"] == h, (c, "traffic file is for other kernel sources")

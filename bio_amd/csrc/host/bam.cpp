@@ -356,6 +356,15 @@ class ResidentPool {
   std::vector<void*> plain_;
 };
 
+// A batch of the resident pipeline's first stage: read and inflated on the device, its bytes at
+// dev->p[kHead, kHead + out_total); nothing found in it yet.
+struct InfBatch {
+  std::shared_ptr<DevStream> dev;
+  size_t out_total = 0;
+  bool eof = false;
+  std::string err;
+};
+
 struct ResBatch {
   std::shared_ptr<DevStream> dev;
   size_t at = 0, size = 0;  // the stream's bytes [at, size); at = the start of a record
@@ -387,6 +396,9 @@ struct BamReader::Impl {
   std::shared_ptr<ResBatch> res_prev;                // (the read-ahead task's) the batch before, for its tail
   std::vector<uint8_t> res_init_tail;                // bytes the host-mode reader had not consumed at the switch
   std::future<std::shared_ptr<ResBatch>> res_next;
+  std::future<std::unique_ptr<InfBatch>> inf_next;   // the batch behind that one: being read and inflated while it is scanned
+  bp_inflater* scan_inflater = nullptr;              // the scan's own stream and buffers (the inflaters are busy with the next batch)
+  double t_scan = 0;                                 // wall seconds of the scan stage (tail, record scan, columns, survey)
   std::atomic<int64_t> res_fallbacks{0};
   double t_readraw = 0, t_inflate = 0, t_take = 0;  // wall seconds inside ReadRaw / Inflate / buffer allocation (BIO_PILEUP_STATS)
   std::shared_ptr<Buf> cur;  // inflated bytes not yet consumed: cur->p[rd, end)
@@ -463,9 +475,11 @@ struct BamReader::Impl {
   ~Impl() {
     if (next.valid()) next.wait();
     if (res_next.valid()) res_next.wait();
+    if (inf_next.valid()) inf_next.wait();
     if (next_raw.valid()) next_raw.wait();
     res_prev.reset();
     for (bp_inflater* x : inflaters) bp_inflate_destroy(x);
+    if (scan_inflater) bp_inflate_destroy(scan_inflater);
     if (f) fclose(f);
   }
 
@@ -623,11 +637,12 @@ struct BamReader::Impl {
     dev_inflate_ms += mx;
   }
 
-  // Resident mode: the next batch read, inflated on the device behind the unconsumed tail of the
-  // batch before it, and scanned there; runs a batch ahead of NextChunk.
-  std::shared_ptr<ResBatch> NextResident() {
-    auto out = std::make_shared<ResBatch>();
-    ResBatch& B = *out;
+  // Resident mode, first stage: the next batch of blocks read and inflated into a device buffer of
+  // its own, kHead bytes in (room for the unconsumed tail of the batch before, which is only known
+  // once that batch has been scanned).  Runs beside the second stage's work on the batch before.
+  std::unique_ptr<InfBatch> InflateStage() {
+    std::unique_ptr<InfBatch> out(new InfBatch);
+    InfBatch& I = *out;
     const int idev = inflate_device.load();
     std::unique_ptr<RawBatch> r = next_raw.valid() ? next_raw.get() : ReadRaw(raw_pos);
     raw_pos = r->end_pos;
@@ -637,46 +652,77 @@ struct BamReader::Impl {
     }
     const auto t_in = std::chrono::steady_clock::now();
     struct Acc { double* a; std::chrono::steady_clock::time_point t; ~Acc() { *a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{&t_inflate, t_in};
-    B.err = r->err;
-    B.eof = r->eof;
-    auto recycle = [&] {
+    I.err = r->err;
+    I.eof = r->eof;
+    I.out_total = r->out_total;
+    if (!I.err.empty()) return out;
+    I.dev = ResidentPool::Get().TakeDev(idev, kHead + r->out_total + 4096);
+    if (!I.dev) { I.err = "bam: out of device memory"; return out; }
+    if (hipSetDevice(idev) != hipSuccess) { I.err = "hipSetDevice failed"; return out; }
+    // (blk_tab offsets are relative to kHead in the batch: out_dev is where offset 0 goes)
+    DeviceInflate(*r, idev, nullptr, I.dev->p + kHead, &I.err);
+    {
       std::lock_guard<std::mutex> lk(spare_mu);
       if (spare.size() < 3) spare.push_back(std::move(r));
-    };
+    }
+    return out;
+  }
+
+  // Second stage: the inflated batch gets the unconsumed tail of the batch before it in front and
+  // is scanned on the device; runs a batch ahead of NextChunk, and the first stage a batch ahead of it.
+  std::shared_ptr<ResBatch> NextResident() {
+    auto out = std::make_shared<ResBatch>();
+    ResBatch& B = *out;
+    const int idev = inflate_device.load();
+    std::unique_ptr<InfBatch> inf = inf_next.valid() ? inf_next.get() : InflateStage();
+    if (inf->err.empty() && !inf->eof) inf_next = std::async(std::launch::async, [this] { return InflateStage(); });
+    const auto t_in = std::chrono::steady_clock::now();
+    struct Acc { double* a; std::chrono::steady_clock::time_point t; ~Acc() { *a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{&t_scan, t_in};
+    B.err = inf->err;
+    B.eof = inf->eof;
     if (!B.err.empty()) return out;
-    const size_t tail = res_prev ? res_prev->size - res_prev->exit : res_init_tail.size();
-    const size_t head = std::max(kHead, (tail + 255) & ~(size_t)255);
-    B.dev = ResidentPool::Get().TakeDev(idev, head + r->out_total + 4096);
-    if (!B.dev) { B.err = "bam: out of device memory"; return out; }
-    B.at = head - tail;
-    B.size = head + r->out_total;
     if (hipSetDevice(idev) != hipSuccess) { B.err = "hipSetDevice failed"; return out; }
+    const size_t tail = res_prev ? res_prev->size - res_prev->exit : res_init_tail.size();
+    size_t head = kHead;
+    B.dev = inf->dev;
+    if (tail > kHead) {
+      // a record longer than the room in front of a batch: the batch moves to a buffer with more
+      head = (tail + 255) & ~(size_t)255;
+      B.dev = ResidentPool::Get().TakeDev(idev, head + inf->out_total + 4096);
+      if (!B.dev) { B.err = "bam: out of device memory"; return out; }
+      if (inf->out_total &&
+          hipMemcpy(B.dev->p + head, inf->dev->p + kHead, inf->out_total, hipMemcpyDeviceToDevice) != hipSuccess) {
+        B.err = "bam: moving a batch on the device failed";
+        return out;
+      }
+    }
+    B.at = head - tail;
+    B.size = head + inf->out_total;
     if (tail) {
       const hipError_t e = res_prev ? hipMemcpy(B.dev->p + B.at, res_prev->dev->p + res_prev->exit, tail, hipMemcpyDeviceToDevice)
                                     : hipMemcpy(B.dev->p + B.at, res_init_tail.data(), tail, hipMemcpyHostToDevice);
       if (e != hipSuccess) { B.err = std::string("bam: copying a batch's tail: ") + hipGetErrorString(e); return out; }
     }
+    // (a device-to-device hipMemcpy may return before the copy has run, and the scan's stream does
+    // not wait for the null stream: make sure the bytes are there, and the buffer moved from is idle)
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { B.err = "bam: device copy failed"; return out; }
     res_init_tail.clear();
     res_init_tail.shrink_to_fit();
-    // (blk_tab offsets are relative to kHead in the batch: out_dev is where offset 0 goes)
-    DeviceInflate(*r, idev, nullptr, B.dev->p + head, &B.err);
-    recycle();
-    if (!B.err.empty()) return out;
-    while (inflaters.empty()) {
-      bp_inflater* x = nullptr;
-      if (bp_inflate_create(idev, &x) != BP_OK) { B.err = bp_inflate_last_error(nullptr); return out; }
-      inflaters.push_back(x);
+    inf.reset();
+    if (!scan_inflater && bp_inflate_create(idev, &scan_inflater) != BP_OK) {
+      B.err = bp_inflate_last_error(nullptr);
+      return out;
     }
     B.cols = ResidentPool::Get().TakeCols((B.size - B.at) / 96 + 4096);
     if (!B.cols) { B.err = "bam: out of memory"; return out; }
     uint64_t exit = B.at;
     int32_t stopped = 0;
-    int rc = B.size > B.at ? bp_bam_scan(inflaters[0], B.dev->p, B.at, B.size, n_ref, &B.cols->c, &B.n, &exit, &stopped) : BP_OK;
+    int rc = B.size > B.at ? bp_bam_scan(scan_inflater, B.dev->p, B.at, B.size, n_ref, &B.cols->c, &B.n, &exit, &stopped) : BP_OK;
     if (rc == 1 || rc == BP_ENOMEM) {
       // a guess of the device walk was wrong (or the records are tiny): this batch is walked on the host
       if (res_fallbacks++ == 0)
         if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
-          fprintf(stderr, "bam: device scan of a batch gave way to the host's walk (%d): %s\n", rc, bp_inflate_last_error(inflaters[0]));
+          fprintf(stderr, "bam: device scan of a batch gave way to the host's walk (%d): %s\n", rc, bp_inflate_last_error(scan_inflater));
       B.cols.reset();
       B.host = BufPool::Get().Take(B.size - B.at + 64, pinned, B.size - B.at + 64 > kStdCap);
       if (!B.host) { B.err = "bam: out of memory"; return out; }
@@ -692,7 +738,7 @@ struct BamReader::Impl {
       B.one_ref = B.host_walk.one_ref;
       B.r0 = B.host_walk.r0; B.p0 = B.host_walk.p0; B.r1 = B.host_walk.r1; B.p1 = B.host_walk.p1;
     } else if (rc != BP_OK) {
-      B.err = bp_inflate_last_error(inflaters[0]);
+      B.err = bp_inflate_last_error(scan_inflater);
       return out;
     } else if (B.n > 0) {
       // what NextChunk's walk surveys, from the columns
@@ -906,10 +952,11 @@ std::string BamReader::FetchHost(Chunk* c) {
   return "";
 }
 
-void BamReader::StageSeconds(double* read_raw, double* inflate, double* take) const {
+void BamReader::StageSeconds(double* read_raw, double* inflate, double* take, double* scan) const {
   *read_raw = impl_->t_readraw;
   *inflate = impl_->t_inflate;
   *take = impl_->t_take;
+  if (scan) *scan = impl_->t_scan;
 }
 
 std::string BamReader::Open(const std::string& path) {

@@ -133,7 +133,7 @@ class BamReader {
   double DeviceInflateSeconds() const;
   // Wall seconds of the read-ahead stages: file reads + header parse, inflate (either kind), and of that
   // the time spent getting output buffers.
-  void StageSeconds(double* read_raw, double* inflate, double* take) const;
+  void StageSeconds(double* read_raw, double* inflate, double* take, double* scan = nullptr) const;
   // True when the next Next() has to bring in more of the file first: the buffers move then,
   // and the pointers of Raw records handed out so far stop being valid.
   bool NextRefills() const;

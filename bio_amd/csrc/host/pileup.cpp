@@ -1017,16 +1017,16 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (s.writer_rev && !(e = s.writer_rev->Close()).empty()) return e;
   }
   st.total_s = Now() - t_start;
-  double sr = 0, si = 0, stk = 0;
-  bam.StageSeconds(&sr, &si, &stk);
+  double sr = 0, si = 0, stk = 0, ssc = 0;
+  bam.StageSeconds(&sr, &si, &stk, &ssc);
   if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
             "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
-            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) resident=%d (host walks %lld) total_s=%.3f\n",
+            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) stage_scan_s=%.3f resident=%d (host walks %lld) total_s=%.3f\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
             index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, st.close_wait_s,
-            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, resident ? 1 : 0, (long long)bam.ResidentFallbacks(), st.total_s);
+            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, ssc, resident ? 1 : 0, (long long)bam.ResidentFallbacks(), st.total_s);
   return "";
 }
 

@@ -522,6 +522,7 @@ class Submitter {
 
 std::string Pileup(const std::string& xampath, const std::string& fapath, const std::string& format,
                    const std::string& out_prefix, const Opts& opts) {
+  const double t_entry = Now();
   // 1. options (pileup.go:974-1025)
   if (opts.Clip < 0 || opts.Clip * 2 >= opts.MaxReadLen) return "Pileup: invalid clip= argument";
   if (opts.MaxReadLen > opts.MaxReadSpan)
@@ -1023,10 +1024,10 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
             "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
-            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) stage_scan_s=%.3f resident=%d (host walks %lld) total_s=%.3f\n",
+            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) stage_scan_s=%.3f resident=%d (host walks %lld) total_s=%.3f (after %.3f s of set-up: header, BED, FASTA, device)\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
             index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, st.close_wait_s,
-            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, ssc, resident ? 1 : 0, (long long)bam.ResidentFallbacks(), st.total_s);
+            st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, ssc, resident ? 1 : 0, (long long)bam.ResidentFallbacks(), st.total_s, t_start - t_entry);
   return "";
 }
 

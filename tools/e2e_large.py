@@ -62,6 +62,7 @@ for mode in os.environ.get("E2E_MODES", "device,host").split(","):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     wall = time.time() - t0
     print(r.stderr.strip()[-2600:], flush=True)
+    print(f"spawned at {t0:.3f}, returned at {t0 + wall:.3f} (epoch seconds)", flush=True)
     outs = sorted(p for p in os.listdir(d) if p.startswith("o."))
     size = sum(os.path.getsize(os.path.join(d, p)) for p in outs)
     h = hashlib.md5()

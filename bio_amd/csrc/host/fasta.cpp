@@ -1,11 +1,16 @@
 // fasta.cpp -- eager FASTA loader with Seq8 encoding and the BAM-header consistency check
 // (reference: encoding/fasta/fasta.go:132-175, biosimd/biosimd_amd64.go:471-511,
 // pileup/common.go:169-225).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cstring>
 
+#include "../par.h"
 #include "bio_host.h"
 
 namespace bio {
@@ -17,7 +22,109 @@ int Fasta::Find(const std::string& name) const {
   return -1;
 }
 
+namespace {
+
+// The common case - an uncompressed file that starts with a header line - on all host threads: the
+// file is mapped, header lines are found block by block, and every sequence is converted in
+// blocks whose output offsets come from a count of the bytes that are not line ends.  (One thread
+// walking a chromosome line by line was 0.25 s of a 1.8 s run, all of it in front of the first
+// record read.)  Same results as the line-by-line loader below, which takes every other file:
+// a '\n' and a '\r' directly in front of one (or at the end of the file) are dropped, empty lines
+// with them; a header's name ends at the first space; a header without sequence lines is replaced
+// by the next one.  Returns false when the file is not of this kind (nothing stored yet).
+bool LoadPlainParallel(const std::string& path, const uint8_t* tab, Fasta* out) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 2) { close(fd); return false; }
+  const size_t size = (size_t)sb.st_size;
+  void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) return false;
+  const char* const d = (const char*)map;
+  if (d[0] != '>') { munmap(map, size); return false; }  // (a gzip file starts 1f 8b; anything odd goes the slow way)
+  const int nt = HostThreads();
+  const size_t kBlock = 4u << 20;
+  // header lines: '>' at the start of a line
+  const size_t nblk = (size + kBlock - 1) / kBlock;
+  std::vector<std::vector<size_t>> found(nblk);
+  bp_par::parallel_for(nblk, nt, [&](size_t b) {
+    const size_t lo = b * kBlock, hi = std::min(size, lo + kBlock);
+    for (const char* p = d + lo; p < d + hi;) {
+      const char* q = (const char*)memchr(p, '>', (size_t)(d + hi - p));
+      if (!q) break;
+      if (q == d || q[-1] == '\n') found[b].push_back((size_t)(q - d));
+      p = q + 1;
+    }
+  });
+  std::vector<size_t> hdr;
+  for (const auto& v : found) hdr.insert(hdr.end(), v.begin(), v.end());
+  auto line_end = [&](size_t i) { return i + 1 < size && d[i] == '\r' ? d[i + 1] == '\n' : (d[i] == '\r' && i + 1 == size); };
+  std::string name;
+  for (size_t k = 0; k < hdr.size(); k++) {
+    const size_t hs = hdr[k];
+    const char* nl = (const char*)memchr(d + hs, '\n', size - hs);
+    size_t he = nl ? (size_t)(nl - d) : size;          // the header line is d[hs, he)
+    const size_t body0 = nl ? he + 1 : size, body1 = k + 1 < hdr.size() ? hdr[k + 1] : size;
+    if (he > hs && d[he - 1] == '\r') he--;
+    const char* sp = (const char*)memchr(d + hs + 1, ' ', he - hs - 1);
+    name.assign(d + hs + 1, sp ? (size_t)(sp - d) - hs - 1 : he - hs - 1);
+    // bytes of the body that are bases: neither '\n' nor a '\r' in front of one
+    const size_t nb = (body1 - body0 + kBlock - 1) / kBlock;
+    std::vector<size_t> cnt(nb + 1, 0);
+    bp_par::parallel_for(nb, nt, [&](size_t b) {
+      const size_t lo = body0 + b * kBlock, hi = std::min(body1, lo + kBlock);
+      size_t drop = 0;
+      for (const char* p = d + lo; p < d + hi;) {
+        const char* q = (const char*)memchr(p, '\n', (size_t)(d + hi - p));
+        if (!q) break;
+        drop++;
+        if (q > d + body0 && q[-1] == '\r') drop++;  // (the '\r' may lie in the block before: it is counted here)
+        p = q + 1;
+      }
+      cnt[b + 1] = hi - lo - drop;
+    });
+    // ... a '\r' counted by the block after it must not count in its own; simplest exact way: fix up
+    // the block ends, and the last line of a file that ends in '\r' without a newline
+    for (size_t b = 0; b < nb; b++) {
+      const size_t hi = std::min(body1, body0 + (b + 1) * kBlock);
+      if (hi < body1 && d[hi - 1] == '\r' && d[hi] == '\n') { cnt[b + 1]--; cnt[b + 2]++; }
+    }
+    if (body1 == size && body1 > body0 && d[size - 1] == '\r') cnt[nb]--;
+    for (size_t b = 0; b < nb; b++) cnt[b + 1] += cnt[b];
+    const size_t total = cnt[nb];
+    if (total == 0 && k + 1 < hdr.size()) continue;  // a header without sequence lines: the next one replaces it
+    std::string seq(total, '\0');
+    bp_par::parallel_for(nb, nt, [&](size_t b) {
+      const size_t lo = body0 + b * kBlock, hi = std::min(body1, lo + kBlock);
+      char* o = &seq[0] + cnt[b];
+      for (size_t i = lo; i < hi; i++) {
+        const char c = d[i];
+        if (c == '\n' || (c == '\r' && line_end(i))) continue;
+        *o++ = (char)tab[(uint8_t)c];
+      }
+    });
+    out->names.push_back(name);
+    out->seqs.push_back(std::move(seq));
+  }
+  munmap(map, size);
+  return true;
+}
+
+}  // namespace
+
 std::string LoadFaSeq8(const std::string& path, Fasta* out) {
+  {
+    uint8_t tab0[256];
+    memset(tab0, 15, sizeof(tab0));
+    tab0['A'] = tab0['a'] = 1;
+    tab0['C'] = tab0['c'] = 2;
+    tab0['G'] = tab0['g'] = 4;
+    tab0['T'] = tab0['t'] = 8;
+    out->names.clear();
+    out->seqs.clear();
+    if (LoadPlainParallel(path, tab0, out)) return "";
+  }
   gzFile f = gzopen(path.c_str(), "rb");  // compress.NewReader sniffs gzip (common.go:179)
   if (!f) return "open " + path + ": no such file or directory";
   gzbuffer(f, 4 << 20);

@@ -146,6 +146,47 @@ def test_parse_cols():
 
 
 # ------------------------------------------------------------------ fasta
+def test_fasta_parallel_loader_equals_line_loader(tmp_path):
+    """A plain file that starts with a header is loaded on all threads from a mapping of the file
+    (fasta.cpp: LoadPlainParallel); the same bytes gzip-compressed take the line-by-line loader.
+    Both must store the same sequences: random line lengths, CRLF and bare CR, empty lines, a
+    header without sequence lines, names cut at the first space, a last line with and without its
+    newline, a sequence of several 4 MiB blocks with line ends on the block edges."""
+    import random
+    rng = random.Random(5)
+    for trial in range(6):
+        parts, names = [], []
+        for k in range(rng.randrange(1, 6)):
+            name = f"c{trial}_{k}"
+            names.append(name)
+            parts.append(f">{name} some description\r\n" if rng.random() < 0.3 else f">{name}\n")
+            if rng.random() < 0.2:
+                continue  # a header without sequence lines
+            n_lines = rng.randrange(1, 40) if trial else 80000
+            for _ in range(n_lines):
+                ln = "".join(rng.choice("ACGTacgtNnRY\r") for _ in range(rng.choice([0, 1, 7, 60, 61, 120])))
+                parts.append(ln + rng.choice(["\n", "\n", "\r\n", "\r\r\n"]))
+        text = "".join(parts)
+        if trial % 2:
+            text = text.rstrip("\n") + rng.choice(["", "\r", "A"])
+        if trial == 0:  # line ends exactly at and around the first 4 MiB edge of the first sequence
+            head = text[: text.index("\n") + 1]
+            body = ("ACGT" * 15 + "\r\n") * ((4 << 20) // 62 + 2)
+            text = head + body + text[len(head):]
+        plain, gz = tmp_path / f"t{trial}.fa", tmp_path / f"t{trial}.fa.gz"
+        plain.write_bytes(text.encode())
+        gz.write_bytes(gzip.compress(text.encode(), 1))
+        for name in names:
+            try:
+                want = host.fasta_seq8(str(gz), name)
+            except ValueError as ex:
+                with pytest.raises(ValueError, match=str(ex)[:20]):
+                    host.fasta_seq8(str(plain), name)
+                continue
+            got = host.fasta_seq8(str(plain), name)
+            assert got.tobytes() == want.tobytes(), (trial, name, len(got), len(want))
+
+
 def test_fasta_seq8(tmp_path):
     p = tmp_path / "r.fa"
     p.write_bytes(b">c1 first contig\nACGTacgt\nNnRY-\n\n>c2\r\nGG\r\nTT\r\n>c3 x y\nA\n")

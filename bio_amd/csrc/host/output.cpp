@@ -141,9 +141,11 @@ class Sink {
   }
   std::string WriteSync(const char* p, size_t n) {
     if (!bgzf_) {
-      // Plain text goes to the file with pwrite at its known offset, large pieces from several
-      // threads at once: a whole-chromosome run writes gigabytes, and one thread copying into the
-      // page cache (5-6 GB/s) was as long as everything else the run does.
+      // Plain text goes to the file with pwrite at its known offset.  BIO_PILEUP_WRITE_THREADS > 1
+      // cuts large pieces over that many threads; the default is one: buffered writes to one file
+      // are serialised by its inode lock (tools/micro/pwrite_bench.c: 8-11 GB/s on the GPU box's
+      // ext4 from 1 thread or 16), and on chr1 30x (8.5 GB of text) one thread measured 1.59-1.66 s
+      // wall for the whole run against 1.76-2.01 s with 8, ten runs on one box.
       const int fd = fileno(f_);
       auto put = [&](const char* q, size_t m, off_t at) {
         while (m) {
@@ -155,7 +157,8 @@ class Sink {
       };
       bool ok = true;
       const size_t kSlice = 4u << 20;
-      const size_t nt = std::min<size_t>({(size_t)std::max(1, threads_), (size_t)8, n / kSlice});
+      static const size_t kMaxT = [] { const char* e = getenv("BIO_PILEUP_WRITE_THREADS"); const long v = e && *e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 1); }();
+      const size_t nt = std::min<size_t>({(size_t)std::max(1, threads_), kMaxT, n / kSlice});
       if (nt <= 1) {
         ok = put(p, n, (off_t)off_);
       } else {

@@ -49,6 +49,9 @@ rc_all, sums = 0, {}
 # E2E_MODES: "device" (the driver's default: BGZF inflate and record scan on the GPU), "scan", "host", "rocprof"
 for mode in os.environ.get("E2E_MODES", "device,host").split(","):
     env = dict(os.environ, BIO_PILEUP_STATS="1", BP_PROFILE="1")
+    if "@" in mode:  # "device@2": that many pwrite threads per piece of text
+        mode, wt = mode.split("@")
+        env["BIO_PILEUP_WRITE_THREADS"] = wt
     if mode == "host":
         env["BIO_PILEUP_HOST_INFLATE"] = "1"
     if mode == "scan":  # device inflate, records found by the host's walk

@@ -6,8 +6,9 @@
 // exactly its range (pileup.go:862-909), and concatenates the per-job rows.  Counts are sums
 // of commutative per-base updates, so a cut into position ranges with enough padding gives
 // the rows of the single-job run (reference -parallelism 1); here a job is a range of one
-// contig of at most JobSpan() positions (one job per human contig), sized for HBM rather than
-// for CPU cores, and jobs run one after another on the device.  In the reference a pair whose
+// contig of at most JobSpan() positions, sized for the pipeline rather than for CPU cores (a
+// job's text can only be rendered and written once it is closed: short jobs let the output start
+// early and run beside the reading), and jobs run one after another on the device.  In the reference a pair whose
 // two reads fall on either side of a job boundary is stitched in neither job, so its output
 // depends mildly on -parallelism when flags are malformed; the padding used here (see step 6)
 // removes that dependence.  `-region` keeps the reference's single unpadded shard
@@ -75,7 +76,9 @@ int64_t JobSpan() {
     long long v = atoll(e);
     if (v > 0) return v;
   }
-  return 1ll << 25;
+  // (chr1 30x, whole run: 2^25 1.58-1.62 s, 2^24 1.58-1.64, 2^23 1.52-1.61, 2^22 1.47-1.57,
+  // 2^21 1.52-1.58, 2^20 1.60-1.62: the output is the long pole and starts when the first job closes)
+  return 1ll << 22;
 }
 
 // BIO_PILEUP_STATS=1 prints one line of counters and stage times to stderr at the end.

@@ -68,7 +68,8 @@ class bp_timing(C.Structure):
 EXPORTS = [
     "bp_init", "bp_device_count", "bp_create", "bp_reserve", "bp_set_bed", "bp_submit", "bp_submit_bam", "bp_finish", "bp_compute", "bp_compute_static",
     "bp_num_rows", "bp_rows", "bp_rows_device", "bp_rows_export", "bp_rows_accumulate", "bp_rows_export_async", "bp_rows_accumulate_async", "bp_stream", "bp_column_sums", "bp_get_timing",
-    "bp_algorithmic_bytes", "bp_last_error", "bp_destroy",
+    "bp_algorithmic_bytes",
+    "bp_job_size", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
     "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch",
     "bp_inflate_create", "bp_inflate_destroy", "bp_inflate_blocks", "bp_inflate_blocks_to", "bp_inflate_device_output", "bp_inflate_stream",
@@ -119,7 +120,8 @@ class bp_bam_columns(C.Structure):
     _fields_ = [("cap", C.c_int64), ("off", C.c_void_p), ("ref_id", C.c_void_p), ("pos", C.c_void_p),
                 ("mate_ref_id", C.c_void_p), ("mate_pos", C.c_void_p), ("flags", C.c_void_p), ("mapq", C.c_void_p),
                 ("l_name", C.c_void_p), ("n_cigar", C.c_void_p), ("l_seq", C.c_void_p), ("bytes", C.c_void_p),
-                ("span", C.c_void_p), ("facts", C.c_void_p)]
+                ("span", C.c_void_p), ("facts", C.c_void_p),
+                ("name_off", C.c_void_p), ("names", C.c_void_p), ("names_cap", C.c_int64)]
 
 
 class bio_basestrand_tsv_row(C.Structure):

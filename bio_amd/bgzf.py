@@ -74,10 +74,11 @@ class Inflater:
             ("flags", np.uint16), ("mapq", np.uint8), ("l_name", np.uint8), ("n_cigar", np.uint32), ("l_seq", np.uint32),
             ("bytes", np.uint32), ("span", np.int32), ("facts", np.uint8))
 
-    def scan(self, first, end, n_ref, cap=None, stream=None):
+    def scan(self, first, end, n_ref, cap=None, stream=None, names=False):
         """bp_bam_scan over the last inflate's device output (or `stream`, a device address): ->
         (rc, cols dict of numpy arrays cut to n, exit, stopped, the bp_bam_columns struct).  rc 1:
-        a guess failed (walk on the host)."""
+        the host has to walk this stream.  names=True: the read names come too (cols["name_off"],
+        n + 1 offsets into cols["names"])."""
         if cap is None:
             cap = (end - first) // 36 + 1
         arrs = {k: np.zeros(cap, t) for k, t in self.COLS}
@@ -85,13 +86,23 @@ class Inflater:
         c.cap = cap
         for k, _ in self.COLS:
             setattr(c, k, arrs[k].ctypes.data)
+        if names:
+            arrs["name_off"] = np.zeros(cap + 1, np.uint32)
+            arrs["names"] = np.zeros(max(end - first, 1), np.uint8)
+            c.name_off = arrs["name_off"].ctypes.data
+            c.names = arrs["names"].ctypes.data
+            c.names_cap = len(arrs["names"])
         n, ex, st = C.c_int64(), C.c_uint64(), C.c_int32()
         rc = self.lib.bp_bam_scan(self.h, stream if stream is not None else self.device_output, first, end, n_ref,
                                   C.byref(c), C.byref(n), C.byref(ex), C.byref(st))
         if rc < 0:
             raise PileupError(rc, self.lib.bp_inflate_last_error(self.h).decode())
         self._keep = arrs
-        return rc, {k: v[:n.value] for k, v in arrs.items()}, ex.value, st.value, c
+        out = {k: v[:n.value] for k, v in arrs.items() if k not in ("name_off", "names")}
+        if names:
+            out["name_off"] = arrs["name_off"][:n.value + 1]
+            out["names"] = arrs["names"][:int(arrs["name_off"][n.value])]
+        return rc, out, ex.value, st.value, c
 
     def timing(self):
         a, b = C.c_float(), C.c_float()

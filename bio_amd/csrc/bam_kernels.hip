@@ -258,6 +258,25 @@ __global__ __launch_bounds__(256) void bam_fields_kernel(const uint8_t* __restri
   }
 }
 
+// Read names, gathered: record i's l_read_name - 1 bytes (the NUL left out) to out + name_off[i].
+// Thread = record; a name is a few dozen bytes.
+__global__ __launch_bounds__(256) void bam_names_kernel(const uint8_t* __restrict__ buf, int64_t n,
+                                                         const uint32_t* __restrict__ off,
+                                                         const uint32_t* __restrict__ name_off,
+                                                         uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* const s = buf + (size_t)off[i] + 36;
+  const uint32_t a = name_off[i], len = name_off[i + 1] - a;
+  for (uint32_t k = 0; k < len; k++) out[a + k] = s[k];
+}
+
+void launch_bam_names(const uint8_t* buf, int64_t n, const uint32_t* off, const uint32_t* name_off, uint8_t* out,
+                      hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(bam_names_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, buf, n, off, name_off, out);
+}
+
 void launch_bam_scan(const uint8_t* buf, uint64_t lo, uint64_t end, int32_t n_ref, int32_t n_stretch, WalkStretch* ws,
                      uint32_t* offs, uint32_t* out4, hipStream_t s) {
   if (n_stretch <= 0) return;

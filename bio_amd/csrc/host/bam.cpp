@@ -261,6 +261,7 @@ struct ColStore {  // the scan's columns of one batch, pinned host memory
   bp_bam_columns c;
   void* block = nullptr;
   size_t cap = 0;
+  size_t names_cap = 0;  // bytes of read names it has room for (0: none wanted, stitching off)
 };
 class ResidentPool {
  public:
@@ -301,12 +302,12 @@ class ResidentPool {
       delete x;
     });
   }
-  std::shared_ptr<ColStore> TakeCols(size_t cap) {
+  std::shared_ptr<ColStore> TakeCols(size_t cap, size_t names_cap = 0) {
     ColStore* c = nullptr;
     {
       std::lock_guard<std::mutex> lk(mu_);
       for (size_t k = 0; k < cols_.size(); k++)
-        if (cols_[k]->cap >= cap) {
+        if (cols_[k]->cap >= cap && cols_[k]->names_cap >= names_cap) {
           c = cols_[k];
           cols_.erase(cols_.begin() + (ptrdiff_t)k);
           break;
@@ -315,10 +316,13 @@ class ResidentPool {
     if (!c) {
       c = new ColStore();
       const size_t N = (std::max<size_t>(cap, 3u << 20) + 63) & ~(size_t)63;
+      // (with names: N + 1 offsets and the bytes behind the columns)
+      const size_t NC = names_cap ? (names_cap + 255) & ~(size_t)255 : 0;
+      const size_t total = N * 48 + (NC ? (N + 64) * 4 + NC : 0);
       void* b = nullptr;
-      if (hipHostMalloc(&b, N * 48, hipHostMallocPortable) != hipSuccess) {
+      if (hipHostMalloc(&b, total, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
-        b = malloc(N * 48);
+        b = malloc(total);
         if (!b) { delete c; return nullptr; }
         c->block = nullptr;  // (not pinned: freed with free)
         plain_.push_back(b);
@@ -341,6 +345,16 @@ class ResidentPool {
       c->c.mapq = q;                    q += N;
       c->c.l_name = q;                  q += N;
       c->c.facts = q;
+      c->c.name_off = nullptr;
+      c->c.names = nullptr;
+      c->c.names_cap = 0;
+      if (NC) {
+        q = (uint8_t*)b + N * 48;
+        c->c.name_off = (uint32_t*)q;   q += (N + 64) * 4;
+        c->c.names = q;
+        c->c.names_cap = (int64_t)NC;
+        c->names_cap = NC;
+      }
     }
     // (column stores are few and of one size: they go back to the pool and stay for the process)
     return std::shared_ptr<ColStore>(c, [this](ColStore* x) {
@@ -392,6 +406,7 @@ struct BamReader::Impl {
   double dev_inflate_ms = 0;
   // resident mode
   bool resident = false, res_done = false;
+  bool want_names = false;   // the scan also fetches the read names (stitching pairs reads by them)
   int32_t n_ref = 0;
   std::shared_ptr<ResBatch> res_prev;                // (the read-ahead task's) the batch before, for its tail
   std::vector<uint8_t> res_init_tail;                // bytes the host-mode reader had not consumed at the switch
@@ -713,7 +728,7 @@ struct BamReader::Impl {
       B.err = bp_inflate_last_error(nullptr);
       return out;
     }
-    B.cols = ResidentPool::Get().TakeCols((B.size - B.at) / 96 + 4096);
+    B.cols = ResidentPool::Get().TakeCols((B.size - B.at) / 96 + 4096, want_names ? (B.size - B.at) / 4 + 4096 : 0);
     if (!B.cols) { B.err = "bam: out of memory"; return out; }
     uint64_t exit = B.at;
     int32_t stopped = 0;
@@ -908,8 +923,9 @@ void BamReader::SetDeviceInflate(int device) { impl_->inflate_device.store(devic
 double BamReader::DeviceInflateSeconds() const { return impl_->dev_inflate_ms * 1e-3; }
 int64_t BamReader::ResidentFallbacks() const { return impl_->res_fallbacks.load(); }
 
-std::string BamReader::StartResident(int device) {
+std::string BamReader::StartResident(int device, bool want_names) {
   Impl& m = *impl_;
+  m.want_names = want_names;
   // what the host-mode reader has read ahead is brought in first: its unconsumed bytes become the
   // tail in front of the first device batch
   if (m.next.valid()) {

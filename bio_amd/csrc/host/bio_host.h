@@ -124,7 +124,7 @@ class BamReader {
   // From here on the inflated stream stays on `device`: blocks are inflated there, records found
   // and their fixed fields read there (bp_bam_scan), and NextChunk hands out device chunks (see
   // Chunk::dev).  After Open(); only NextChunk / FetchHost may follow (no Next, no Seek).
-  std::string StartResident(int device);
+  std::string StartResident(int device, bool want_names = false);
   // The bytes of a device chunk copied to host memory (c->data set; c->hold keeps them too).
   std::string FetchHost(Chunk* c);
   // Batches whose device scan failed and were walked on the host instead.

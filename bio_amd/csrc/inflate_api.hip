@@ -26,6 +26,8 @@ void launch_bgzf_crc(const uint8_t* out, const InflateBlock* blks, int n_blocks,
                      uint32_t* status, hipStream_t s);
 void launch_bam_scan(const uint8_t* buf, uint64_t lo, uint64_t end, int32_t n_ref, int32_t n_stretch, WalkStretch* ws,
                      uint32_t* offs, uint32_t* out4, hipStream_t s);
+void launch_bam_names(const uint8_t* buf, int64_t n, const uint32_t* off, const uint32_t* name_off, uint8_t* out,
+                      hipStream_t s);
 void launch_bam_fields(const uint8_t* buf, int32_t n_stretch, const WalkStretch* ws, const uint32_t* offs,
                        const BamColumns& C, hipStream_t s);
 }
@@ -47,6 +49,7 @@ struct bp_inflater {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   Buf comp, blks, out, status;  // device
   Buf walk, offs, cols;         // device: the record scan's stretches, offsets and columns
+  Buf names;                    // device: name offsets (n + 1 dwords), then the gathered names
   uint32_t* h_scan = nullptr;   // pinned: the verifier's four words
   uint32_t* tables = nullptr;   // device: CRC tables
   uint32_t* h_status = nullptr; // pinned
@@ -311,6 +314,29 @@ int bp_bam_scan(bp_inflater* f, const uint8_t* stream, uint64_t first, uint64_t 
   INF_TRY(f, hipMemcpyAsync(cols->l_name, C.lname, m, hipMemcpyDeviceToHost, f->stream));
   INF_TRY(f, hipMemcpyAsync(cols->facts, C.facts, m, hipMemcpyDeviceToHost, f->stream));
   INF_TRY(f, hipStreamSynchronize(f->stream));
+  if (cols->names) {
+    // the read names, for callers that pair reads (stitching): offsets = running sum of the name
+    // lengths (host, from the column just fetched), then one gather on the device
+    if (!cols->name_off) return ifail(f, BP_EINVAL, "bp_bam_scan: names wanted without name_off");
+    uint64_t total = 0;
+    for (size_t i = 0; i < m; i++) {
+      cols->name_off[i] = (uint32_t)total;
+      total += (cols->facts[i] & 4) ? 0u : cols->l_name[i] ? cols->l_name[i] - 1u : 0u;  // (fields outside the block: no name taken)
+    }
+    cols->name_off[m] = (uint32_t)total;
+    if (total > (uint64_t)cols->names_cap || total > 0xffffffffull)
+      return ifail(f, BP_ENOMEM, "bp_bam_scan: %llu bytes of read names, room for %lld", (unsigned long long)total,
+                   (long long)cols->names_cap);
+    if (total) {
+      const size_t ob = ((m + 1) * 4 + 255) & ~(size_t)255;
+      if (int rc = grow(f, f->names, ob + (size_t)total)) return rc;
+      INF_TRY(f, hipMemcpyAsync(f->names.p, cols->name_off, (m + 1) * 4, hipMemcpyHostToDevice, f->stream));
+      launch_bam_names(stream, n, C.off, (const uint32_t*)f->names.p, (uint8_t*)f->names.p + ob, f->stream);
+      INF_TRY(f, hipGetLastError());
+      INF_TRY(f, hipMemcpyAsync(cols->names, (const uint8_t*)f->names.p + ob, (size_t)total, hipMemcpyDeviceToHost, f->stream));
+      INF_TRY(f, hipStreamSynchronize(f->stream));
+    }
+  }
   return BP_OK;
 }
 

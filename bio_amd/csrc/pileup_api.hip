@@ -625,14 +625,19 @@ struct Src {
   const uint32_t* rec_bytes = nullptr; // stream mode: 4 + block_size
   const int32_t* span = nullptr;       // stream mode: cigar_span() of every record, worked out when its fields were read
   const uint8_t* cig_facts = nullptr;  // ... bit 0 simple, bit 1 has an op outside MIDNSH
+  const uint8_t* names = nullptr;      // device-stream mode: the read names gathered by bp_bam_scan (no NULs) ...
+  const uint32_t* name_off = nullptr;  // ... record i's at names + name_off[i]
 
   const uint8_t* cigar(int64_t i) const {
     return raw ? raw + off[i] + 36 + l_name[i] : (const uint8_t*)(b->cigar + b->cigar_off[i]);
   }
-  bool has_names() const { return raw || (b && b->name && b->name_off); }
-  const uint8_t* name(int64_t i) const { return raw ? raw + off[i] + 36 : b->name + b->name_off[i]; }
+  bool has_names() const { return raw || names || (b && b->name && b->name_off); }
+  const uint8_t* name(int64_t i) const {
+    return raw ? raw + off[i] + 36 : names ? names + name_off[i] : b->name + b->name_off[i];
+  }
   uint32_t name_len(int64_t i) const {
-    return raw ? (l_name[i] ? l_name[i] - 1u : 0u) : (uint32_t)(b->name_off[i + 1] - b->name_off[i]);
+    return raw ? (l_name[i] ? l_name[i] - 1u : 0u) : names ? name_off[i + 1] - name_off[i]
+                                                           : (uint32_t)(b->name_off[i + 1] - b->name_off[i]);
   }
 };
 
@@ -1505,7 +1510,9 @@ int bp_submit_bam_device(bp_handle* h, const uint8_t* stream, size_t n_bytes, co
                          int64_t first, int64_t n) {
   if (!h || !c || n < 0 || first < 0 || (n > 0 && !stream)) return fail(h, BP_EINVAL, "bp_submit_bam_device: bad argument");
   if (n_bytes > 0xffffffffull) return fail(h, BP_EINVAL, "bp_submit_bam_device: more than 4 GiB in one call");
-  if (h->o.stitch) return fail(h, BP_EINVAL, "bp_submit_bam_device: stitch mode needs the read names on the host (use bp_submit_bam)");
+  if (h->o.stitch && !(c->names && c->name_off))
+    return fail(h, BP_EINVAL, "bp_submit_bam_device: stitch mode needs the read names on the host (bp_bam_scan with "
+                              "cols->names, or bp_submit_bam)");
   try {
     // what bp_submit_bam checks while it reads the fields: every record inside the stream, its
     // fields inside its block (the scan says so), CIGARs of ops the walk knows
@@ -1540,6 +1547,10 @@ int bp_submit_bam_device(bp_handle* h, const uint8_t* stream, size_t n_bytes, co
     S.rec_bytes = c->bytes + first;
     S.span = c->span + first;
     S.cig_facts = c->facts + first;
+    if (c->names && c->name_off) {
+      S.names = c->names;
+      S.name_off = c->name_off + first;
+    }
     return guarded_submit(h, S, "bp_submit_bam_device");
   } catch (const std::bad_alloc&) {
     return fail(h, BP_ENOMEM, "bp_submit_bam_device: out of host memory");
@@ -2076,6 +2087,13 @@ int bp_get_timing(const bp_handle* h, bp_timing* out) {
   out->submit_scan_ms = (float)(h->scan_s * 1e3);
   out->submit_pack_ms = (float)(h->pack_s * 1e3);
   out->stitch_resolve_ms = (float)h->resolve_ms;
+  return BP_OK;
+}
+
+int bp_job_size(const bp_handle* h, int64_t* n_records, int64_t* payload_bytes) {
+  if (!h || !n_records || !payload_bytes) return BP_EINVAL;
+  *n_records = h->n_reads;
+  *payload_bytes = (int64_t)h->blob_used * 8;
   return BP_OK;
 }
 

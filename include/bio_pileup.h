@@ -268,6 +268,11 @@ int bp_get_timing(const bp_handle* h, bp_timing* out);
 /* Algorithmic bytes of the resident job per SURVEY.md section 8(d):
  * sum_reads(32 + 4*n_cigar + ceil(l_seq/2) + l_seq) + 44*rows. */
 int64_t bp_algorithmic_bytes(const bp_handle* h);
+/* Records submitted so far and the device bytes their payloads take: what a caller that opens one
+ * job after another of similar size passes to the next job's bp_reserve (the C++ driver does), so
+ * that its buffers are taken at their final size instead of grown step by step.  No counterpart
+ * in the reference (Go slices grow by themselves). */
+int bp_job_size(const bp_handle* h, int64_t* n_records, int64_t* payload_bytes);
 
 const char* bp_last_error(const bp_handle* h); /* h may be NULL: last create/init error */
 void bp_destroy(bp_handle* h);
@@ -335,6 +340,13 @@ typedef struct bp_bam_columns {
   uint32_t* bytes;  /* 4 + block_size */
   int32_t* span;    /* reference bases the CIGAR consumes (sam.Cigar.Lengths) */
   uint8_t* facts;   /* bit 0: one M op; bit 1: an op outside MIDNSH; bit 2: the fields do not fit the block */
+  /* Optional (names NULL: not wanted): the read names, one after the other without their NULs,
+   * record i's at names[name_off[i], name_off[i + 1]) - what stitching pairs reads by
+   * (firstread.go:135-152), so that a stitched job can take its records from the device stream too.
+   * name_off has room for cap + 1 entries, names for names_cap bytes. */
+  uint32_t* name_off;
+  uint8_t* names;
+  int64_t names_cap;
 } bp_bam_columns;
 /* Scans stream bytes [first, end) on the device (device pointer `stream`, on the inflater's
  * device; `first` = the start of a record) for whole records: *n of them, columns filled, *exit
@@ -344,14 +356,15 @@ typedef struct bp_bam_columns {
  * whose guess was wrong or missing walked again from the right place, so the records found are
  * those of a serial walk.  Returns 1 (nothing filled) when a stretch holds more records than the
  * scan has room for (records of a few bytes: not BAM reads) and the caller should walk this
- * stream on the host, a negative BP_E* code on errors (BP_ENOMEM: more records than cols->cap). */
+ * stream on the host, a negative BP_E* code on errors (BP_ENOMEM: more records than cols->cap, or
+ * more name bytes than cols->names_cap). */
 int bp_bam_scan(bp_inflater* f, const uint8_t* stream, uint64_t first, uint64_t end, int32_t n_ref,
                 bp_bam_columns* cols, int64_t* n, uint64_t* exit, int32_t* stopped);
 /* bp_submit_bam for records [first_record, first_record + n) of such a scan: `stream` is the
  * DEVICE address of the stream the columns' offsets refer to (on the job's device); nothing of
- * the records is read on the host.  Only for jobs without stitching (the mate table is keyed by
- * read names, which are in the stream) and for records whose facts carry neither bit 1 nor bit 2
- * (the caller hands such records over with bp_submit_bam from a host copy).  The pack kernel
+ * the records is read on the host.  A job with stitching needs the scan's names (cols->names: the
+ * mate table is keyed by read names).  Not for records whose facts carry bit 1 or bit 2 (the
+ * caller hands such records over with bp_submit_bam from a host copy).  The pack kernel
  * loads whole aligned 4-byte words: the word that holds the stream's last byte must be readable
  * (any hipMalloc'ed buffer is). */
 int bp_submit_bam_device(bp_handle* h, const uint8_t* stream, size_t n_bytes, const bp_bam_columns* cols,

@@ -284,15 +284,16 @@ def test_job_cuts_with_halo_change_nothing(tmp_path, stitch, monkeypatch):
         assert c.read("sub.basestrand.tsv") == want, span
 
 
-def test_reader_modes_write_the_same_files(tmp_path, monkeypatch, capfd):
+@pytest.mark.parametrize("stitch", [False, True])
+def test_reader_modes_write_the_same_files(tmp_path, monkeypatch, capfd, stitch):
     """The three ways the BAM reaches the pack kernel - inflated stream resident on the device with
-    records found there (the default without stitching), device inflate with the host's record walk
+    records found there (the default; stitched runs get the read names from the scan too), device inflate with the host's record walk
     (BIO_PILEUP_HOST_SCAN=1), zlib on host threads (BIO_PILEUP_HOST_INFLATE=1) - write the same
     bytes, also with one-block batches (records straddle every batch edge) and small jobs; the
     stats line says which one ran."""
     c = Case(tmp_path, seed=77)
-    o = Opts(BedPath=c.bed_path, MinBaseQual=20, MaxReadLen=150, MaxReadSpan=300)
-    want = render_basestrand(c.oracle(min_base_qual=20, max_read_len=150, max_read_span=300),
+    o = Opts(BedPath=c.bed_path, MinBaseQual=20, MaxReadLen=150, MaxReadSpan=300, Stitch=stitch)
+    want = render_basestrand(c.oracle(min_base_qual=20, max_read_len=150, max_read_span=300, stitch=int(stitch)),
                              c.ref_names, c.ref_ascii)
     monkeypatch.setenv("BIO_PILEUP_STATS", "1")
     for blocks, span in ((0, 0), (1, 0), (2, 700)):

@@ -274,4 +274,25 @@ def test_device_record_scan_and_submit(tmp_path):
             j.set_bed(bed)
             with pytest.raises(snp.PileupError, match="stitch mode needs the read names"):
                 j.submit_bam_device(inf.device_output, total, cstruct, 0, 10)
+        # ... and with the names gathered by the scan a stitched job pairs its reads from the device
+        # stream as from host bytes: the names are the stream's, the rows the oracle's
+        rc, ncols, ex, stopped, nstruct = inf.scan(q, total, 2, names=True)
+        assert rc == 0 and len(ncols["off"]) == rb.n and len(ncols["name_off"]) == rb.n + 1
+        for i in list(range(0, rb.n, 997)) + [rb.n - 1]:
+            o, ln = int(ncols["off"][i]), int(ncols["l_name"][i])
+            a, b = int(ncols["name_off"][i]), int(ncols["name_off"][i + 1])
+            assert b - a == ln - 1 and bytes(ncols["names"][a:b]) == stream[o + 36:o + 36 + ln - 1], i
+        sopts = O.make_opts(stitch=1, min_base_qual=20, clip=1)
+        with snp.PileupJob(sopts, [L, 1000]) as a, snp.PileupJob(sopts, [L, 1000]) as b:
+            a.set_bed(bed)
+            b.set_bed(bed)
+            a.submit_bam(np.frombuffer(stream, np.uint8), ncols["off"])
+            third = rb.n // 3
+            for lo, hi in ((0, third), (third, third + 1), (third + 1, rb.n)):  # (pairs split over calls)
+                b.submit_bam_device(inf.device_output, total, nstruct, lo, hi - lo)
+            a.finish()
+            b.finish()
+            ra, rbw = a.rows(), b.rows()
+            assert (ra[2] == rbw[2]).all()
+            assert (rbw[2] == O.pileup(sopts, [L, 1000], bed, rb)[2]).all()
     sb.close()

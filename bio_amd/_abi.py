@@ -71,7 +71,7 @@ EXPORTS = [
     "bp_algorithmic_bytes",
     "bp_job_size", "bp_last_error", "bp_destroy",
     "bp_per_read_build", "bp_per_read_total", "bp_per_read_offsets", "bp_per_read_features",
-    "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch",
+    "bp_set_ref_seq8", "bp_render_text_bound", "bp_render_text", "bp_render_fetch", "bp_render_bgzf_bound", "bp_render_fetch_bgzf", "bp_deflate_bgzf_bound", "bp_deflate_bgzf", "bp_deflate_codes",
     "bp_inflate_create", "bp_inflate_destroy", "bp_inflate_blocks", "bp_inflate_blocks_to", "bp_inflate_device_output", "bp_inflate_stream",
     "bp_inflate_timing", "bp_inflate_last_error", "bp_bam_scan", "bp_submit_bam_device",
 ]
@@ -198,6 +198,16 @@ def load():
     lib.bp_render_text.restype = C.c_int
     lib.bp_render_fetch.argtypes = [H, C.c_void_p, C.c_size_t]
     lib.bp_render_fetch.restype = C.c_int
+    lib.bp_render_bgzf_bound.argtypes = [H]
+    lib.bp_render_bgzf_bound.restype = C.c_int64
+    lib.bp_render_fetch_bgzf.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.bp_render_fetch_bgzf.restype = C.c_int
+    lib.bp_deflate_bgzf_bound.argtypes = [C.c_size_t]
+    lib.bp_deflate_bgzf_bound.restype = C.c_size_t
+    lib.bp_deflate_bgzf.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.bp_deflate_bgzf.restype = C.c_int
+    lib.bp_deflate_codes.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.bp_deflate_codes.restype = C.c_int
     lib.bp_per_read_build.argtypes = [H]
     lib.bp_per_read_build.restype = C.c_int
     lib.bp_per_read_total.argtypes = [H]

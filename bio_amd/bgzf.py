@@ -104,6 +104,18 @@ class Inflater:
             out["names"] = arrs["names"][:int(arrs["name_off"][n.value])]
         return rc, out, ex.value, st.value, c
 
+    def deflate(self, data):
+        """bp_deflate_bgzf: bytes-like -> uint8 array of complete BGZF members (no EOF member)."""
+        data = np.ascontiguousarray(np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data, np.uint8)
+        cap = int(self.lib.bp_deflate_bgzf_bound(data.size))
+        out = np.empty(max(cap, 1), np.uint8)
+        n = C.c_size_t()
+        rc = self.lib.bp_deflate_bgzf(self.h, data.ctypes.data if data.size else None, data.size, out.ctypes.data, cap,
+                                      C.byref(n))
+        if rc != 0:
+            raise PileupError(rc, self.lib.bp_inflate_last_error(self.h).decode())
+        return out[:n.value]
+
     def timing(self):
         a, b = C.c_float(), C.c_float()
         self.lib.bp_inflate_timing(self.h, C.byref(a), C.byref(b))

@@ -271,6 +271,12 @@ class RowWriter {
     (void)which; (void)text;
     return "pileup output: this format takes rows, not text";
   }
+  // The same lines as complete BGZF members (compressed on the device, bp_render_fetch_bgzf): only
+  // for the -bgz formats, whose files are runs of such members.
+  virtual std::string WriteBgzf(int which, TextString&& members) {
+    (void)which; (void)members;
+    return "pileup output: this format takes rows, not BGZF members";
+  }
   virtual std::string Close() = 0;
 };
 // ConvertPileupRowsToTSV (output.go:42-300): <prefix>.ref.tsv[.gz] + <prefix>.alt.tsv[.gz]

@@ -86,6 +86,19 @@ class Sink {
     return "";
   }
   std::string Write(const char* p, size_t n) { return Write(TextString(p, n)); }
+  // Complete BGZF members (compressed elsewhere: on the device) go to the file as they are, behind
+  // whatever text is still waiting to be compressed here.
+  std::string WriteMembers(TextString&& members) {
+    if (!bgzf_) return "write " + path_ + ": BGZF members for a plain file";
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return queued_ < kMaxQueued || !err_.empty(); });
+    if (!err_.empty()) return err_;
+    queued_ += members.size();
+    q_.push_back(std::move(members));
+    raw_.push_back(q_.size() - 1 + popped_);
+    cv_.notify_all();
+    return "";
+  }
   TextString Spare() {
     std::unique_lock<std::mutex> lk(mu_);
     if (spare_.empty()) return TextString();
@@ -120,14 +133,20 @@ class Sink {
   void Run() {
     for (;;) {
       TextString text;
+      bool raw = false;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return !q_.empty() || done_; });
         if (q_.empty()) return;
         text = std::move(q_.front());
         q_.pop_front();
+        if (!raw_.empty() && raw_.front() == popped_) {
+          raw = true;
+          raw_.pop_front();
+        }
+        popped_++;
       }
-      std::string e = WriteSync(text.data(), text.size());
+      std::string e = raw ? WriteMembersSync(text.data(), text.size()) : WriteSync(text.data(), text.size());
       std::unique_lock<std::mutex> lk(mu_);
       queued_ -= text.size();
       if (spare_.size() < 4 && text.capacity() >= (1u << 20)) {  // large buffers go round again
@@ -177,9 +196,19 @@ class Sink {
     if (pend_.size() >= kBlock * kBatch * (size_t)threads_) return Compress(false);
     return "";
   }
+  std::string WriteMembersSync(const char* p, size_t n) {
+    if (!pend_.empty()) {
+      std::string err = Compress(true);
+      if (!err.empty()) return err;
+    }
+    if (fwrite(p, 1, n, f_) != n) return "write " + path_ + ": short write";
+    return "";
+  }
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<TextString> q_;
+  std::deque<size_t> raw_;  // which of the queued items (counted from the first ever queued) are BGZF members
+  size_t popped_ = 0;
   std::vector<TextString> spare_;
   size_t queued_ = 0;
   bool done_ = false;
@@ -202,7 +231,9 @@ class Sink {
       for (size_t b = t; b < nblk; b += nt) {
         const size_t off = b * kBlock, len = std::min(kBlock, pend_.size() - off);
         std::string& o = out[b];
-        o.resize(18 + compressBound((uLong)len) + 8);
+        // (64 bytes beyond zlib's bound: libdeflate wants its own, 9 bytes of end padding among them, and
+        // gives up on a short incompressible block - a header line by itself - without them)
+        o.resize(18 + compressBound((uLong)len) + 64 + 8);
         size_t clen = 0;
         if (comp) {
           clen = ld.compress(comp, pend_.data() + off, len, &o[18], o.size() - 18 - 8);
@@ -297,6 +328,7 @@ class Tsv {
   }
   std::string Append(TextString&& text) { return sink_.Write(std::move(text)); }
   std::string Append(std::string&& text) { return sink_.Write(text.data(), text.size()); }
+  std::string AppendMembers(TextString&& members) { return sink_.WriteMembers(std::move(members)); }
   TextString Spare() { return sink_.Spare(); }
   std::string Close() { return sink_.Close(); }
 
@@ -400,6 +432,10 @@ class TsvWriter : public RowWriter {
   std::string WriteText(int which, TextString&& text) override {
     if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
     return which == 0 ? ref_.Append(std::move(text)) : alt_.Append(std::move(text));
+  }
+  std::string WriteBgzf(int which, TextString&& members) override {
+    if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
+    return which == 0 ? ref_.AppendMembers(std::move(members)) : alt_.AppendMembers(std::move(members));
   }
   std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                     const uint64_t* off, const bp_per_read* feats) override {
@@ -526,6 +562,10 @@ class BasestrandTsvWriter : public RowWriter {
   std::string WriteText(int, TextString&& text) override {
     if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
     return w_.Append(std::move(text));
+  }
+  std::string WriteBgzf(int, TextString&& members) override {
+    if (cols_ & kPerReadMask) return "pileup output: per-read columns are rendered on the host";
+    return w_.AppendMembers(std::move(members));
   }
   std::string Write(const int32_t* ref_id, const int32_t* pos, const uint32_t* vals, int64_t n,
                     const uint64_t* off, const bp_per_read* feats) override {

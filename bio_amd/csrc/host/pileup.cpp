@@ -156,6 +156,7 @@ class Driver {
   bool per_read = false;  // a per-read column set is requested (pCtx.perReadNeeded)
   // basestrand-tsv without per-read columns: the rows become text on the device
   bool device_text = false;
+  bool text_bgzf = false;  // ... and compresses them into BGZF members (-bgz formats, bp_render_fetch_bgzf)
   bool text_tsv = false;   // ... of the tsv format (two files) rather than basestrand-tsv
   int32_t text_cols = 0;   // its -cols bits
   const std::vector<const std::string*>* ref_seqs = nullptr;
@@ -316,9 +317,18 @@ class Driver {
             size_t len = 0;
             if (bp_render_text(h, kind | sel, text_cols, first, m, nullptr, 0, &len) != BP_OK) return HandleErr(h);
             TextString text = w->SpareText(which);
-            text.resize(len);
-            if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
-            std::string err = w->WriteText(which, std::move(text));
+            std::string err;
+            if (text_bgzf) {  // compressed where it was rendered: a fifth of the bytes cross the bus and reach the file
+              text.resize((size_t)bp_render_bgzf_bound(h));
+              size_t clen = 0;
+              if (bp_render_fetch_bgzf(h, &text[0], text.size(), &clen) != BP_OK) return HandleErr(h);
+              text.resize(clen);
+              err = w->WriteBgzf(which, std::move(text));
+            } else {
+              text.resize(len);
+              if (bp_render_fetch(h, &text[0], text.size()) != BP_OK) return HandleErr(h);
+              err = w->WriteText(which, std::move(text));
+            }
             if (!err.empty()) return err;
           }
         }
@@ -693,6 +703,9 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   const int n_stream = opts.PerStrand && !one_pass ? 2 : 1;
   drv.streams.resize((size_t)n_stream);
   const bool bgz = fmt == kTsvBgz || fmt == kBsTsvBgz;
+  // -bgz: the device compresses what it renders (BIO_PILEUP_HOST_DEFLATE=1: libdeflate/zlib level 6 on
+  // the host's threads as before - files a fifth smaller, runs several times longer)
+  drv.text_bgzf = bgz && drv.device_text && !getenv("BIO_PILEUP_HOST_DEFLATE");
   auto new_writer = [&](const std::string& path, std::string* err) {
     return tsv_format ? NewTsvWriter(path, cols, bgz, hd.ref_names, ref_seqs, err)
                       : NewBasestrandTsvWriter(path, cols, bgz, hd.ref_names, ref_seqs, err);

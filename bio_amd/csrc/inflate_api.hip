@@ -17,6 +17,7 @@
 
 #include "../../include/bio_pileup.h"
 #include "bam_device.h"
+#include "deflate_api.h"
 #include "inflate_device.h"
 
 namespace bp {
@@ -50,6 +51,8 @@ struct bp_inflater {
   Buf comp, blks, out, status;  // device
   Buf walk, offs, cols;         // device: the record scan's stretches, offsets and columns
   Buf names;                    // device: name offsets (n + 1 dwords), then the gathered names
+  Buf dfl_in;                   // device: bp_deflate_bgzf's input
+  DeflateScratch* dfl = nullptr;
   uint32_t* h_scan = nullptr;   // pinned: the verifier's four words
   uint32_t* tables = nullptr;   // device: CRC tables
   uint32_t* h_status = nullptr; // pinned
@@ -104,21 +107,6 @@ const char* status_text(uint32_t s) {
   }
 }
 
-// T and the four "advance by 256 zero bytes" tables of bgzf_crc_kernel
-void crc_tables(uint32_t* t /*[1280]*/) {
-  for (uint32_t n = 0; n < 256; n++) {
-    uint32_t c = n;
-    for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-    t[n] = c;
-  }
-  for (int q = 0; q < 4; q++)
-    for (uint32_t b = 0; b < 256; b++) {
-      uint32_t v = b << (8 * q);
-      for (int k = 0; k < 256; k++) v = t[v & 0xffu] ^ (v >> 8);
-      t[256 + 256 * q + b] = v;
-    }
-}
-
 }  // namespace
 
 extern "C" {
@@ -158,8 +146,9 @@ void bp_inflate_destroy(bp_inflater* f) {
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   if (f->h_scan) (void)hipHostFree(f->h_scan);
-  for (Buf* b : {&f->comp, &f->blks, &f->out, &f->status, &f->walk, &f->offs, &f->cols})
+  for (Buf* b : {&f->comp, &f->blks, &f->out, &f->status, &f->walk, &f->offs, &f->cols, &f->names, &f->dfl_in})
     if (b->p) (void)hipFree(b->p);
+  deflate_scratch_free(f->dfl);
   if (f->tables) (void)hipFree(f->tables);
   if (f->h_status) (void)hipHostFree(f->h_status);
   for (hipEvent_t ev : f->ev)
@@ -352,6 +341,29 @@ int bp_inflate_timing(const bp_inflater* f, float* inflate_ms, float* crc_ms) {
   if (!f) return BP_EINVAL;
   if (inflate_ms) *inflate_ms = f->inflate_ms;
   if (crc_ms) *crc_ms = f->crc_ms;
+  return BP_OK;
+}
+
+size_t bp_deflate_bgzf_bound(size_t n) { return deflate_bgzf_bound(n); }
+
+int bp_deflate_bgzf(bp_inflater* f, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* len) {
+  if (!f || !len || (n && (!in || !out))) return ifail(f, BP_EINVAL, "bp_deflate_bgzf: null argument");
+  *len = 0;
+  if (n == 0) return BP_OK;
+  if (cap < deflate_bgzf_bound(n))
+    return ifail(f, BP_EINVAL, "bp_deflate_bgzf: buffer of %zu bytes for %zu of input (see bp_deflate_bgzf_bound)", cap, n);
+  INF_TRY(f, hipSetDevice(f->device));
+  if (!f->dfl) f->dfl = deflate_scratch_new();
+  if (int rc = grow(f, f->dfl_in, n + 256)) return rc;
+  INF_TRY(f, hipMemcpyAsync(f->dfl_in.p, in, n, hipMemcpyHostToDevice, f->stream));
+  const uint8_t* d_out = nullptr;
+  size_t total = 0;
+  std::string err;
+  if (int rc = deflate_bgzf_device(f->dfl, (const uint8_t*)f->dfl_in.p, n, f->stream, &d_out, &total, &err))
+    return ifail(f, rc, "bp_deflate_bgzf: %s", err.c_str());
+  INF_TRY(f, hipMemcpyAsync(out, d_out, total, hipMemcpyDeviceToHost, f->stream));
+  INF_TRY(f, hipStreamSynchronize(f->stream));
+  *len = total;
   return BP_OK;
 }
 

@@ -28,6 +28,7 @@
 
 #include <algorithm>
 
+#include "crc_device.h"
 #include "inflate_device.h"
 
 namespace bp {
@@ -492,55 +493,9 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
   const int lane = (int)(threadIdx.x & 63);
   const int wave = (int)rfl(threadIdx.x >> 6);
   const int nw = (int)gridDim.x * 4;
-  auto adv1 = [&](uint32_t v) { return T[v & 0xffu] ^ (v >> 8); };
   for (int b = (int)blockIdx.x * 4 + wave; b < n_blocks; b += nw) {
     const InflateBlock blk = blks[b];
-    const uint32_t n = blk.out_len;
-    const uint8_t* base = out + blk.out_off;
-    uint32_t crc;
-    if (n < 4) {
-      crc = 0xffffffffu;
-      for (uint32_t k = 0; k < n; k++) crc = adv1(crc ^ base[k]);
-      crc = ~crc;
-    } else {
-      // the block as a message with h zero bytes in front, so that its dwords are aligned ones
-      const uint32_t h = (uint32_t)((uintptr_t)base & 3);
-      const uint32_t* a = (const uint32_t*)(base - h);
-      const uint32_t np = h + n, ndw = np >> 2, tail = np & 3;
-      uint32_t s = 0;
-      int last = -1;
-      for (uint32_t k = (uint32_t)lane; k < ndw; k += 64) {
-        uint32_t d = a[k];
-        // the initial state 0xffffffff is the first four bytes of the message inverted
-        if (k == 0) d = (d & (0xffffffffu << (8 * h))) ^ (0xffffffffu << (8 * h));
-        if (k == 1 && h) d ^= 0xffffffffu >> (32 - 8 * h);
-        const uint32_t v = s ^ d;
-        if (k + 64 < ndw) {
-          s = W[0][v & 0xffu] ^ W[1][(v >> 8) & 0xffu] ^ W[2][(v >> 16) & 0xffu] ^ W[3][v >> 24];
-        } else {
-          s = adv1(adv1(adv1(adv1(v))));
-          last = (int)k;
-        }
-      }
-      if (last >= 0) {
-        const uint32_t m = (ndw - 1 - (uint32_t)last) * 4 + tail;  // bytes behind this lane's last dword
-        for (uint32_t k = 0; k < m; k++) s = adv1(s);
-      }
-      if (lane == 63 && tail) {
-        uint32_t t = 0;
-        const uint8_t* tp = (const uint8_t*)(a + ndw);
-        // (when the message has fewer than two dwords the inverted prefix reaches into the tail)
-        for (uint32_t k = 0; k < tail; k++) {
-          uint32_t byte = tp[k];
-          if (ndw == 1 && h) byte ^= (0xffffffffu >> (32 - 8 * h) >> (8 * k)) & 0xffu;
-          t = adv1(t ^ byte);
-        }
-        s ^= t;
-      }
-#pragma unroll
-      for (int d = 32; d; d >>= 1) s ^= (uint32_t)__shfl_xor((int)s, d, 64);
-      crc = ~s;
-    }
+    const uint32_t crc = wave_crc32(out + blk.out_off, blk.out_len, T, W, lane);
     if (lane == 0 && crc != blk.crc32 && status[b] == INF_OK) status[b] = INF_BAD_CRC;
   }
 }

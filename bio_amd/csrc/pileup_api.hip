@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/bio_pileup.h"
+#include "deflate_api.h"
 #include "pack_device.h"
 #include "par.h"
 #include "pileup_device.h"
@@ -376,6 +377,7 @@ struct bp_handle {
   DevBuf d_cores, d_blob, d_mate, d_windows, d_r0, d_r1, d_iv_start, d_iv_end, d_iv_row, d_rows,
       d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_tile_lo, d_pr_feat, d_seq8, d_refname, d_txt_len, d_txt_tile, d_txt_out, d_items, d_coarse, d_raw, d_pack;
   bool per_read_valid = false;
+  DeflateScratch* dfl = nullptr;        // bp_render_fetch_bgzf
   int32_t seq_ref = -1, seq_start = 0;  // bp_set_ref_seq8
   int64_t seq_len = 0;
   bool iv_ref_uploaded = false;
@@ -2081,6 +2083,28 @@ int bp_render_fetch(bp_handle* h, char* out, size_t cap) {
   return BP_OK;
 }
 
+int64_t bp_render_bgzf_bound(const bp_handle* h) { return h ? (int64_t)deflate_bgzf_bound(h->txt_len) : -1; }
+
+int bp_render_fetch_bgzf(bp_handle* h, char* out, size_t cap, size_t* len) {
+  if (!h || !len || (!out && h->txt_len)) return fail(h, BP_EINVAL, "bp_render_fetch_bgzf: null argument");
+  *len = 0;
+  if (h->txt_len == 0) return BP_OK;
+  if (cap < deflate_bgzf_bound(h->txt_len))
+    return fail(h, BP_EINVAL, "bp_render_fetch_bgzf: buffer of %llu bytes for %llu of text (see bp_render_bgzf_bound)",
+                (unsigned long long)cap, (unsigned long long)h->txt_len);
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!h->dfl) h->dfl = deflate_scratch_new();
+  const uint8_t* d_out = nullptr;
+  size_t total = 0;
+  std::string err;
+  // (d_txt_out ends in 256 bytes of slack: the tokeniser's dword loads may look past the text)
+  if (int rc = deflate_bgzf_device(h->dfl, (const uint8_t*)h->d_txt_out.p, h->txt_len, h->stream, &d_out, &total, &err))
+    return fail(h, rc, "bp_render_fetch_bgzf: %s", err.c_str());
+  HIP_TRY(h, hipMemcpy(out, d_out, total, hipMemcpyDeviceToHost));
+  *len = total;
+  return BP_OK;
+}
+
 int bp_get_timing(const bp_handle* h, bp_timing* out) {
   if (!h || !out) return BP_EINVAL;
   *out = h->timing;
@@ -2137,6 +2161,7 @@ void bp_destroy(bp_handle* h) {
       free_stage(s);
     }
   }
+  deflate_scratch_free(h->dfl);
   for (hipEvent_t e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->host_err) (void)hipHostFree(h->host_err);

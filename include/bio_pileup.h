@@ -262,6 +262,16 @@ int64_t bp_render_text_bound(const bp_handle* h, int32_t kind, int64_t n_rows);
 int bp_render_text(bp_handle* h, int32_t kind, int32_t cols, int64_t first, int64_t n, char* out, size_t cap,
                    size_t* len);
 int bp_render_fetch(bp_handle* h, char* out, size_t cap);
+/* The same text as BGZF: what the `-bgz` formats write (bgzf.NewWriter around the tsv writer,
+ * pileup/snp/output.go:66-82, :388-392; the reference compresses on `parallelism` host threads).  The
+ * text the last bp_render_text(out = NULL) left on the device is compressed there and copied to `out`
+ * (at least bp_render_bgzf_bound(h) bytes) as a run of complete BGZF members (SAM spec 4.1; up to
+ * 0xff00 bytes of text each, DEFLATE with Huffman codes built for this text, stored when that is
+ * shorter; no EOF member: the file's writer appends it once).  *len = bytes written.  The bytes are
+ * this compressor's own; what is pinned is that they inflate to exactly the text bp_render_fetch
+ * returns. */
+int64_t bp_render_bgzf_bound(const bp_handle* h);
+int bp_render_fetch_bgzf(bp_handle* h, char* out, size_t cap, size_t* len);
 
 int bp_get_timing(const bp_handle* h, bp_timing* out);
 
@@ -317,6 +327,18 @@ const uint8_t* bp_inflate_device_output(const bp_inflater* f);
 int bp_inflate_stream(bp_inflater* f, void** stream);
 /* HIP-event times of the last call's inflate and CRC kernels */
 int bp_inflate_timing(const bp_inflater* f, float* inflate_ms, float* crc_ms);
+/* The writer's side (the counterpart of bp_inflate; bgzf.Writer in the reference's output path,
+ * output.go:70-71, :391): n bytes of host memory compressed on the inflater's device into complete
+ * BGZF members of up to 0xff00 input bytes each, copied to `out` (at least bp_deflate_bgzf_bound(n)
+ * bytes; no EOF member).  Synchronous. */
+size_t bp_deflate_bgzf_bound(size_t n);
+/* The host half of that writer by itself (no device call; exported so that it can be tested without
+ * one): from symbol counts hist[0..286) (literals, end of block, lengths; RFC 1951 3.2.5) and
+ * hist[288..318) (distances) the canonical Huffman codes, lengths limited to 15 bits, and the dynamic
+ * block header that announces them (RFC 1951 3.2.7, BFINAL set).  out: 288 + 32 codes (bit-reversed,
+ * length in bits 16-19), the header's length in bits, then its bits in 128 dwords. */
+int bp_deflate_codes(const uint32_t* hist, uint64_t n_members, uint32_t* out);
+int bp_deflate_bgzf(bp_inflater* f, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* len);
 const char* bp_inflate_last_error(const bp_inflater* f);
 
 /* ---- BAM record scan on the device (second half) -----------------------

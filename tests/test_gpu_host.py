@@ -262,6 +262,30 @@ def test_cols_and_bgz(tmp_path):
     assert c.read("o.basestrand.tsv.gz") == render_basestrand(c.oracle(), c.ref_names, c.ref_ascii)
 
 
+def test_bgz_by_the_device_and_by_the_host_inflate_to_the_plain_files(tmp_path, monkeypatch):
+    """-bgz: the device compresses the lines it renders (bp_render_fetch_bgzf); BIO_PILEUP_HOST_DEFLATE=1
+    keeps the host's deflate.  Both files are BGZF with the EOF member and inflate to the plain format's
+    bytes; small jobs make many short runs of members."""
+    import gzip
+    c = Case(tmp_path, seed=31)
+    for fmt, names in (("basestrand-tsv", ["basestrand.tsv"]), ("tsv", ["ref.tsv", "alt.tsv"])):
+        o = Opts(BedPath=c.bed_path, Cols="dpref,dpalt") if fmt == "tsv" else Opts(BedPath=c.bed_path)
+        host.pileup(c.bam, c.fa, fmt, str(tmp_path / "p"), o)
+        monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", "900")
+        host.pileup(c.bam, c.fa, fmt + "-bgz", str(tmp_path / "d"), o)
+        monkeypatch.delenv("BIO_PILEUP_JOB_SPAN")
+        monkeypatch.setenv("BIO_PILEUP_HOST_DEFLATE", "1")
+        host.pileup(c.bam, c.fa, fmt + "-bgz", str(tmp_path / "h"), o)
+        monkeypatch.delenv("BIO_PILEUP_HOST_DEFLATE")
+        for nm in names:
+            plain = open(tmp_path / ("p." + nm), "rb").read()
+            assert len(plain) > 1000
+            for k in "dh":
+                raw = open(tmp_path / (k + "." + nm + ".gz"), "rb").read()
+                assert raw.endswith(bamio._EOF) and raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC"
+                assert gzip.decompress(raw) == plain, (fmt, nm, k)
+
+
 @pytest.mark.parametrize("stitch", [False, True])
 def test_job_cuts_with_halo_change_nothing(tmp_path, stitch, monkeypatch):
     """Cutting contigs into many small device jobs (halo = max-read-span, like the reference's

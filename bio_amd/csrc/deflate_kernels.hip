@@ -10,9 +10,11 @@
 //
 //   deflate_tokens_kernel   LZ77.  A member (0xff00 bytes of text) is cut into 8 segments, a WAVE
 //                           each.  64 consecutive positions per step, lane = position: hash of the
-//                           4 bytes there, candidate = the last earlier position with that hash
-//                           (LDS table of 4096 16-bit positions per wave, primed with the 512
-//                           bytes in front of the segment), match length by comparing dwords.
+//                           4 bytes there, candidates = the last four earlier positions with that
+//                           hash (LDS table of 1024 x 4 16-bit positions per wave, primed with the
+//                           512 bytes in front of the segment) and the window's own first position
+//                           with it, match lengths by comparing dwords, the longest wins; a longer
+//                           match one byte on makes this byte a literal (one step of zlib's lazy rule).
 //                           Which positions start a token is a serial question (a match skips
 //                           the positions it covers): the wave answers it on the scalar unit,
 //                           v_readlane of the step from position to position, typically 10-15
@@ -39,7 +41,13 @@ namespace bp {
 
 namespace {
 
-constexpr int kHashBits = 12;
+// Match search, measured on 268 MB of basestrand-tsv lines (tools/deflate_bench.py; zlib -1 4.56x, -6 6.11x):
+// one candidate per hash 4.90x; + one step of lazy evaluation 5.11x; two candidates 5.34x; + the
+// window's own first position per hash 5.45x; four candidates 5.59x (tokeniser 3.2 -> 7 ms).
+constexpr int kWays = 4;          // candidates kept per hash: the last 1, 2 or 4 positions
+constexpr int kHashBits = kWays == 4 ? 10 : kWays == 2 ? 11 : 12;  // 8 KB of LDS per wave either way
+constexpr bool kLazy = true;      // a longer match one byte on turns this byte into a literal
+constexpr bool kIntra = true;     // candidates inside the current window of 64 positions
 constexpr uint32_t kWarm = 512;
 constexpr uint32_t kMinMatch = 4, kMaxMatch = 258, kMaxDist = 32768;
 
@@ -50,6 +58,18 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p) {
   const uintptr_t a = (uintptr_t)p;
   const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
   return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)a & 3u);
+}
+
+// 16 bytes at any address (reads up to 19 bytes behind them)
+__device__ __forceinline__ void ld128(const uint8_t* p, uint32_t (&o)[4]) {
+  const uintptr_t a = (uintptr_t)p;
+  const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+  const uint32_t sh = (uint32_t)a & 3u;
+  const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+  o[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  o[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  o[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+  o[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -89,13 +109,16 @@ __device__ __forceinline__ void dist_symbol(uint32_t dm1, uint32_t& sym, uint32_
 __global__ __launch_bounds__(256) void deflate_tokens_kernel(const uint8_t* __restrict__ text, uint64_t n_text,
                                                               uint32_t* __restrict__ tok, uint32_t* __restrict__ ntok,
                                                               uint32_t* __restrict__ hist) {
-  __shared__ uint16_t tabs[4][1 << kHashBits];
+  __shared__ uint16_t tabs[4][kWays << kHashBits];
   __shared__ uint32_t lh[kDflHist];
+  __shared__ uint32_t firsts[4][256];
   const int lane = (int)(threadIdx.x & 63);
   const int wave = (int)rfl(threadIdx.x >> 6);
   uint16_t* const tab = tabs[wave];
+  uint32_t* const first = firsts[wave];  // the lowest position of the current window per (short) hash
+  for (int k = lane; k < 256; k += 64) first[k] = 0xffffffffu;
   for (int k = (int)threadIdx.x; k < kDflHist; k += 256) lh[k] = 0;
-  for (int k = lane; k < (1 << kHashBits) / 2; k += 64) ((uint32_t*)tab)[k] = 0xffffffffu;
+  for (int k = lane; k < (kWays << kHashBits) / 2; k += 64) ((uint32_t*)tab)[k] = 0xffffffffu;
   __syncthreads();
   const uint64_t n_members = (n_text + kDflMember - 1) / kDflMember;
   const uint64_t unit = (uint64_t)blockIdx.x * 4 + (uint64_t)wave;
@@ -112,39 +135,113 @@ __global__ __launch_bounds__(256) void deflate_tokens_kernel(const uint8_t* __re
     if (s0 < s1) {
       auto hash = [](uint32_t v) { return (v * 2654435761u) >> (32 - kHashBits); };
       // the bytes in front of the segment (the neighbouring wave's) prime the table
-      for (uint32_t p = (s0 > kWarm ? s0 - kWarm : 0u) + (uint32_t)lane; p < s0; p += 64) tab[hash(ld32(base + p))] = (uint16_t)p;
+      // a bucket is {newest, the one before} when two are kept
+      auto lookup = [&](uint32_t hv, uint32_t (&c)[4]) {
+        c[0] = c[1] = c[2] = c[3] = 0xffffu;
+        if (kWays == 4) {
+          const uint2 e = ((const uint2*)tab)[hv];
+          c[0] = e.x & 0xffffu; c[1] = e.x >> 16; c[2] = e.y & 0xffffu; c[3] = e.y >> 16;
+        } else if (kWays == 2) {
+          const uint32_t e = ((const uint32_t*)tab)[hv];
+          c[0] = e & 0xffffu;
+          c[1] = e >> 16;
+        } else {
+          c[0] = tab[hv];
+        }
+      };
+      auto insert = [&](uint32_t hv, uint32_t pos, const uint32_t (&c)[4]) {
+        if (kWays == 4) ((uint2*)tab)[hv] = make_uint2(pos | (c[0] << 16), c[1] | (c[2] << 16));
+        else if (kWays == 2) ((uint32_t*)tab)[hv] = pos | (c[0] << 16);
+        else tab[hv] = (uint16_t)pos;
+      };
+      // equal leading bytes of two 16-byte stretches
+      auto head16 = [](const uint32_t (&a)[4], const uint32_t (&b)[4]) {
+        const uint32_t x0 = a[0] ^ b[0], x1 = a[1] ^ b[1], x2 = a[2] ^ b[2], x3 = a[3] ^ b[3];
+        if (x0) return (uint32_t)__builtin_ctz(x0) >> 3;
+        if (x1) return 4u + ((uint32_t)__builtin_ctz(x1) >> 3);
+        if (x2) return 8u + ((uint32_t)__builtin_ctz(x2) >> 3);
+        if (x3) return 12u + ((uint32_t)__builtin_ctz(x3) >> 3);
+        return 16u;
+      };
+      // a match known to hold for its first 16 bytes, followed further (16 bytes a round trip)
+      auto extend = [&](uint32_t cand, uint32_t pos, uint32_t maxlen) {
+        uint32_t l = 16;
+        while (l < maxlen) {
+          uint32_t a[4], b[4];
+          ld128(base + cand + l, a);
+          ld128(base + pos + l, b);
+          const uint32_t h = head16(a, b);
+          l += h;
+          if (h < 16) break;
+        }
+        return l;
+      };
+      for (uint32_t p = (s0 > kWarm ? s0 - kWarm : 0u) + (uint32_t)lane; p < s0; p += 64) {
+        const uint32_t hv = hash(ld32(base + p));
+        uint32_t c[4];
+        lookup(hv, c);
+        insert(hv, p, c);
+      }
       uint32_t carry = 0;  // positions from the window's start on that an earlier match covers
       for (uint32_t p = s0; p < s1; p += 64) {
         const uint32_t pos = p + (uint32_t)lane;
         const bool in = pos < s1;
         const uint32_t v = in ? ld32(base + pos) : 0u;
         const bool hashable = in && pos + 4 <= mlen;
-        uint32_t cand = 0xffffu;
+        uint32_t c[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
         const uint32_t hv = hash(v);
-        if (hashable) cand = tab[hv];
+        if (hashable) lookup(hv, c);
         __builtin_amdgcn_wave_barrier();  // every lane has read before any writes (the LDS works a wave's requests in order)
-        if (hashable) tab[hv] = (uint16_t)pos;
+        if (hashable) insert(hv, pos, c);
+        // the table knows earlier windows only; inside the window, the first position with the same
+        // (8-bit) hash is a candidate for all later ones
+        uint32_t cw = 0xffffu;
+        if (kIntra) {
+          if (hashable) atomicMin(&first[hv & 255u], pos);
+          __builtin_amdgcn_wave_barrier();
+          if (hashable) {
+            cw = first[hv & 255u];
+            if (cw >= pos) cw = 0xffffu;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (hashable) first[hv & 255u] = 0xffffffffu;
+        }
         if (carry >= 64) {  // the whole window lies inside a match
           carry -= 64;
           continue;
         }
         const uint32_t room = in ? s1 - pos : 0u;
         const uint32_t maxlen = room < kMaxMatch ? room : kMaxMatch;
-        uint32_t len = 0;
-        if (cand != 0xffffu && maxlen >= kMinMatch && pos - cand <= kMaxDist) {
-          const uint8_t* const a = base + cand;
-          const uint8_t* const b = base + pos;
-          uint32_t l = 0;
-          while (l < maxlen) {
-            const uint32_t x = ld32(a + l) ^ ld32(b + l);
-            if (x) {
-              l += (uint32_t)__builtin_ctz(x) >> 3;
-              break;
-            }
-            l += 4;
+        // All candidates at once: 16 bytes of each (one round trip for the lot; most matches of this
+        // text end inside them), the longest wins, the nearest on equal lengths (the window's own
+        // first, then the table's from the newest on).  Only a match that holds for all 16 is followed.
+        uint32_t len = 0, cand = 0xffffu;
+        if (maxlen >= kMinMatch) {
+          uint32_t cs[kWays + 1], ls[kWays + 1];
+          cs[0] = kIntra ? cw : 0xffffu;
+#pragma unroll
+          for (int k = 0; k < kWays; k++) cs[k + 1] = c[k];
+          uint32_t B[4];
+          ld128(base + pos, B);
+#pragma unroll
+          for (int k = 0; k <= kWays; k++) {
+            const bool ok = cs[k] != 0xffffu && pos - cs[k] <= kMaxDist;
+            uint32_t A[4];
+            ld128(base + (ok ? cs[k] : pos), A);
+            ls[k] = ok ? head16(A, B) : 0u;
           }
-          l = l < maxlen ? l : maxlen;
-          if (l >= kMinMatch) len = l;
+#pragma unroll
+          for (int k = 0; k <= kWays; k++) {
+            uint32_t l = ls[k];
+            if (l == 16 && maxlen > 16 && len < maxlen) l = extend(cs[k], pos, maxlen);
+            l = l < maxlen ? l : maxlen;
+            if (l > len) { len = l; cand = cs[k]; }
+          }
+          if (len < kMinMatch) len = 0;
+        }
+        if (kLazy) {  // a longer match one byte on: this byte goes out as a literal (zlib's lazy evaluation, one step)
+          const uint32_t nl = (uint32_t)__shfl_down((int)len, 1, 64);
+          if (lane < 63 && len && nl > len) len = 0;
         }
         // which positions start a token: from `carry` on, every token to the next
         const uint32_t step = len ? len : 1u;

@@ -210,6 +210,37 @@ def e2e_block(rb, L, B, o, opts_kw, job, cpu_sample_mb, with_cpu):
                                 "device_inflate_kernels_s": float(m.group(3)), "resident": resident,
                                 "host_walks": int(m.group(5)), "total_s": float(m.group(6))} if m else None,
                "inputs_made_in_s": round(make_s, 1)}
+        if not (o.MinBaseQual or o.Clip or o.Stitch):
+            # the same run with -format basestrand-tsv-bgz: the lines leave the device as BGZF members
+            # (deflate_kernels.hip); the file's first members and its last one are inflated here (zlib)
+            # and compared with the plain file
+            import struct
+            import zlib
+            flags_z = ["-bed", bedp, "-format", "basestrand-tsv-bgz"]
+            t0 = time.time()
+            r = subprocess.run([exe, *flags_z, "-out", os.path.join(d, "z"), bam, fa], capture_output=True, text=True)
+            wall_z = time.time() - t0
+            if r.returncode != 0:
+                raise SystemExit("e2e: bio-pileup -format basestrand-tsv-bgz failed: " + r.stderr[-500:])
+            zp = os.path.join(d, "z.basestrand.tsv.gz")
+            z_bytes = os.path.getsize(zp)
+            with open(zp, "rb") as f, open(outp, "rb") as g:
+                got, p = b"", 0
+                buf = f.read(64 << 16)
+                for _ in range(48):
+                    total = struct.unpack_from("<H", buf, p + 16)[0] + 1
+                    got += zlib.decompressobj(-15).decompress(buf[p + 18:p + total - 8])
+                    p += total
+                if got != g.read(len(got)) or len(got) < 40 * 0xff00:  # (the header line is a short member of its own)
+                    raise SystemExit("e2e: the first BGZF members do not inflate to the head of the plain file")
+                f.seek(-28, 2)
+                if f.read() != bamio._EOF:
+                    raise SystemExit("e2e: no BGZF EOF member at the end of the -bgz file")
+            blk["bgz"] = {"value": round(B / wall_z / 1e9, 3), "unit": "Gbase/s", "wall_s": round(wall_z, 2),
+                          "what": f"the same run with -format basestrand-tsv-bgz: the lines compressed on the device "
+                                  f"(bp_render_fetch_bgzf), {z_bytes / 1e9:.2f} GB written ({out_bytes / z_bytes:.2f}x); "
+                                  f"first 48 members inflate (zlib) to the head of the plain file"}
+            os.remove(zp)
         for pth in (outp, bam):
             os.remove(pth)
         if with_cpu:

@@ -11,6 +11,9 @@ namespace bp {
 struct DeflateScratch;  // device and pinned buffers of one caller; grows, never shrinks
 DeflateScratch* deflate_scratch_new();
 void deflate_scratch_free(DeflateScratch* sc);
+// the same through a pool per device (for callers that come and go, like a job's handle); the device is current
+DeflateScratch* deflate_scratch_acquire(int device);
+void deflate_scratch_release(int device, DeflateScratch* sc);
 
 // bytes that n bytes of text take at most as BGZF members (every member can fall back to stored)
 size_t deflate_bgzf_bound(size_t n);

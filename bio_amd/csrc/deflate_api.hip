@@ -7,7 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/bio_pileup.h"
@@ -225,6 +227,49 @@ struct DeflateScratch {
 };
 
 DeflateScratch* deflate_scratch_new() { return new DeflateScratch(); }
+
+// A job's handle lives for one job, the buffers are worth keeping (half a gigabyte of device memory
+// and three pinned allocations per chunk size): handles borrow a scratch from a small pool per
+// device and give it back.  What is still in the pool when the process ends stays there.
+namespace {
+struct ScratchPool {
+  std::mutex mu;
+  std::vector<std::pair<int, DeflateScratch*>> v;
+};
+ScratchPool& scratch_pool() {
+  static ScratchPool* p = new ScratchPool();
+  return *p;
+}
+}  // namespace
+
+DeflateScratch* deflate_scratch_acquire(int device) {
+  ScratchPool& sp = scratch_pool();
+  {
+    std::unique_lock<std::mutex> lk(sp.mu);
+    for (size_t k = 0; k < sp.v.size(); k++)
+      if (sp.v[k].first == device) {
+        DeflateScratch* sc = sp.v[k].second;
+        sp.v.erase(sp.v.begin() + (long)k);
+        return sc;
+      }
+  }
+  return new DeflateScratch();
+}
+
+void deflate_scratch_release(int device, DeflateScratch* sc) {
+  if (!sc) return;
+  ScratchPool& sp = scratch_pool();
+  {
+    std::unique_lock<std::mutex> lk(sp.mu);
+    size_t same = 0;
+    for (const auto& e : sp.v) same += e.first == device;
+    if (same < 4) {
+      sp.v.emplace_back(device, sc);
+      return;
+    }
+  }
+  deflate_scratch_free(sc);
+}
 
 void deflate_scratch_free(DeflateScratch* sc) {
   if (!sc) return;

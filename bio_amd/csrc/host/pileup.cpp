@@ -319,10 +319,10 @@ class Driver {
             TextString text = w->SpareText(which);
             std::string err;
             if (text_bgzf) {  // compressed where it was rendered: a fifth of the bytes cross the bus and reach the file
-              text.resize((size_t)bp_render_bgzf_bound(h));
-              size_t clen = 0;
-              if (bp_render_fetch_bgzf(h, &text[0], text.size(), &clen) != BP_OK) return HandleErr(h);
+              size_t clen = 0;  // (first the length, then a string of just that size: growing one fills it)
+              if (bp_render_fetch_bgzf(h, nullptr, 0, &clen) != BP_OK) return HandleErr(h);
               text.resize(clen);
+              if (bp_render_fetch_bgzf(h, &text[0], text.size(), &clen) != BP_OK) return HandleErr(h);
               err = w->WriteBgzf(which, std::move(text));
             } else {
               text.resize(len);
@@ -423,6 +423,7 @@ class Closer {
     if (th_.joinable()) th_.join();
   }
   double busy_s() const { return busy_s_; }
+  double part_s(int k) const { return part_s_[k]; }  // 0 compute (bp_finish), 1 output (text to the sink), 2 handles freed
 
  private:
   struct Item { Job job; std::vector<bp_handle*> hs; JobRows rows; };
@@ -442,14 +443,18 @@ class Closer {
         e = gate_->err;
       }
       if (e.empty()) e = drv_->ComputeJob(it->hs);
+      const double t1 = Now();
       {
         std::unique_lock<std::mutex> gl(gate_->mu);
         gate_->cv.wait(gl, [&] { return gate_->next_seq == it->job.seq; });
         if (gate_->err.empty()) gate_->err = e;
         e = gate_->err;
       }
+      const double t2 = Now();
       if (e.empty()) e = drv_->OutputJob(it->job, it->hs, it->rows);
+      const double t3 = Now();
       Driver::FreeHandles(it->hs);
+      part_s_[0] += t1 - t0; part_s_[1] += t3 - t2; part_s_[2] += Now() - t3;
       {
         std::unique_lock<std::mutex> gl(gate_->mu);
         if (gate_->err.empty()) gate_->err = e;
@@ -468,7 +473,7 @@ class Closer {
   std::condition_variable cv_;
   std::deque<Item> q_;
   bool done_ = false;
-  double busy_s_ = 0;
+  double busy_s_ = 0, part_s_[3] = {0, 0, 0};
   std::thread th_;
 };
 
@@ -1028,12 +1033,15 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     if (!open && !(err = open_job()).empty()) break;
     err = close_job();
   }
+  double cpart[3] = {0, 0, 0};
   {
     const double t0 = Now();
     (void)drain();
     for (auto& c : closers) c->Join();
     st.close_wait_s += Now() - t0;
     for (auto& c : closers) st.close_s += c->busy_s();
+    for (auto& c : closers)
+      for (int k = 0; k < 3; k++) cpart[k] += c->part_s(k);
     if (err.empty()) err = gate.err;
   }
   if (!err.empty()) {
@@ -1052,9 +1060,9 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
             "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
-            "threads; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) stage_scan_s=%.3f resident=%d (host walks %lld) total_s=%.3f (after %.3f s of set-up: header, BED, FASTA, device)\n",
+            "threads: compute %.3f, text out %.3f, handles freed %.3f; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) stage_scan_s=%.3f resident=%d (host walks %lld) total_s=%.3f (after %.3f s of set-up: header, BED, FASTA, device)\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
-            index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, st.close_wait_s,
+            index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, cpart[0], cpart[1], cpart[2], st.close_wait_s,
             st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, ssc, resident ? 1 : 0, (long long)bam.ResidentFallbacks(), st.total_s, t_start - t_entry);
   return "";
 }

@@ -378,6 +378,8 @@ struct bp_handle {
       d_err, d_sums, d_qthr, d_dbg, d_ref_first, d_iv_ref, d_pr_off, d_pr_tiles, d_pr_tile0, d_pr_tile_lo, d_pr_feat, d_seq8, d_refname, d_txt_len, d_txt_tile, d_txt_out, d_items, d_coarse, d_raw, d_pack;
   bool per_read_valid = false;
   DeflateScratch* dfl = nullptr;        // bp_render_fetch_bgzf
+  const uint8_t* dfl_out = nullptr;     // the members of the text on the device (in dfl's memory), until the next bp_render_text
+  size_t dfl_len = 0;
   int32_t seq_ref = -1, seq_start = 0;  // bp_set_ref_seq8
   int64_t seq_len = 0;
   bool iv_ref_uploaded = false;
@@ -2018,6 +2020,7 @@ int bp_render_text(bp_handle* h, int32_t kind, int32_t cols, int64_t first, int6
                 (long long)(first + n), (long long)h->n_rows);
   *len = 0;
   h->txt_len = 0;
+  h->dfl_out = nullptr;
   if (n == 0) return BP_OK;
   if (out && (int64_t)cap < bp_render_text_bound(h, kind, n))
     return fail(h, BP_EINVAL, "bp_render_text: buffer of %llu bytes for %lld rows (see bp_render_text_bound)",
@@ -2086,22 +2089,28 @@ int bp_render_fetch(bp_handle* h, char* out, size_t cap) {
 int64_t bp_render_bgzf_bound(const bp_handle* h) { return h ? (int64_t)deflate_bgzf_bound(h->txt_len) : -1; }
 
 int bp_render_fetch_bgzf(bp_handle* h, char* out, size_t cap, size_t* len) {
-  if (!h || !len || (!out && h->txt_len)) return fail(h, BP_EINVAL, "bp_render_fetch_bgzf: null argument");
+  if (!h || !len) return fail(h, BP_EINVAL, "bp_render_fetch_bgzf: null argument");
   *len = 0;
   if (h->txt_len == 0) return BP_OK;
-  if (cap < deflate_bgzf_bound(h->txt_len))
-    return fail(h, BP_EINVAL, "bp_render_fetch_bgzf: buffer of %llu bytes for %llu of text (see bp_render_bgzf_bound)",
-                (unsigned long long)cap, (unsigned long long)h->txt_len);
   HIP_TRY(h, hipSetDevice(h->device));
-  if (!h->dfl) h->dfl = deflate_scratch_new();
-  const uint8_t* d_out = nullptr;
-  size_t total = 0;
-  std::string err;
-  // (d_txt_out ends in 256 bytes of slack: the tokeniser's dword loads may look past the text)
-  if (int rc = deflate_bgzf_device(h->dfl, (const uint8_t*)h->d_txt_out.p, h->txt_len, h->stream, &d_out, &total, &err))
-    return fail(h, rc, "bp_render_fetch_bgzf: %s", err.c_str());
-  HIP_TRY(h, hipMemcpy(out, d_out, total, hipMemcpyDeviceToHost));
-  *len = total;
+  if (!h->dfl_out) {  // (a call with out = NULL has left the members of this text on the device otherwise)
+    if (out && cap < deflate_bgzf_bound(h->txt_len))
+      return fail(h, BP_EINVAL, "bp_render_fetch_bgzf: buffer of %llu bytes for %llu of text (see bp_render_bgzf_bound)",
+                  (unsigned long long)cap, (unsigned long long)h->txt_len);
+    if (!h->dfl) h->dfl = deflate_scratch_acquire(h->device);
+    std::string err;
+    // (d_txt_out ends in 256 bytes of slack: the tokeniser's dword loads may look past the text)
+    if (int rc = deflate_bgzf_device(h->dfl, (const uint8_t*)h->d_txt_out.p, h->txt_len, h->stream, &h->dfl_out, &h->dfl_len, &err)) {
+      h->dfl_out = nullptr;
+      return fail(h, rc, "bp_render_fetch_bgzf: %s", err.c_str());
+    }
+  }
+  *len = h->dfl_len;
+  if (!out) return BP_OK;
+  if (cap < h->dfl_len)
+    return fail(h, BP_EINVAL, "bp_render_fetch_bgzf: buffer of %llu bytes for %llu of members", (unsigned long long)cap,
+                (unsigned long long)h->dfl_len);
+  HIP_TRY(h, hipMemcpy(out, h->dfl_out, h->dfl_len, hipMemcpyDeviceToHost));
   return BP_OK;
 }
 
@@ -2161,7 +2170,7 @@ void bp_destroy(bp_handle* h) {
       free_stage(s);
     }
   }
-  deflate_scratch_free(h->dfl);
+  deflate_scratch_release(h->device, h->dfl);
   for (hipEvent_t e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->host_err) (void)hipHostFree(h->host_err);

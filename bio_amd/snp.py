@@ -158,12 +158,26 @@ class PileupJob:
         a = np.ascontiguousarray(seq8, np.uint8)
         self._check(self.lib.bp_set_ref_seq8(self.h, ref_id, start, a.ctypes.data, len(a)))
 
-    def render_text(self, first=0, n=None, kind=0, cols=0):
+    def render_text(self, first=0, n=None, kind=0, cols=0, bgzf=None):
         """Output lines of rows [first, first+n), rendered on the device (bytes).  kind: 0
         basestrand-tsv, 1 .ref.tsv, 2 .alt.tsv; cols: the -cols bits (1 dpref, 2 dpalt, 64 highq,
-        128 lowq)."""
+        128 lowq).  bgzf: the lines as BGZF members compressed on the device instead
+        (bp_render_fetch_bgzf) - "one" in one call with a buffer of bp_render_bgzf_bound bytes, "two"
+        asking for the length first."""
         if n is None:
             n = self.num_rows - first
+        if bgzf:
+            ln = C.c_size_t(0)
+            self._check(self.lib.bp_render_text(self.h, kind, cols, first, n, None, 0, C.byref(ln)))
+            clen = C.c_size_t(0)
+            if bgzf == "two":
+                self._check(self.lib.bp_render_fetch_bgzf(self.h, None, 0, C.byref(clen)))
+                cap = clen.value
+            else:
+                cap = int(self.lib.bp_render_bgzf_bound(self.h))
+            buf = C.create_string_buffer(max(cap, 1))
+            self._check(self.lib.bp_render_fetch_bgzf(self.h, buf, cap, C.byref(clen)))
+            return buf.raw[:clen.value]
         cap = int(self.lib.bp_render_text_bound(self.h, kind, n))
         buf = C.create_string_buffer(max(cap, 1))
         ln = C.c_size_t(0)

@@ -267,7 +267,9 @@ int bp_render_fetch(bp_handle* h, char* out, size_t cap);
  * text the last bp_render_text(out = NULL) left on the device is compressed there and copied to `out`
  * (at least bp_render_bgzf_bound(h) bytes) as a run of complete BGZF members (SAM spec 4.1; up to
  * 0xff00 bytes of text each, DEFLATE with Huffman codes built for this text, stored when that is
- * shorter; no EOF member: the file's writer appends it once).  *len = bytes written.  The bytes are
+ * shorter; no EOF member: the file's writer appends it once).  *len = bytes written.  With out = NULL
+ * the members stay on the device, *len says how long they are, and a second call copies them to a
+ * buffer of that size (until the next bp_render_text).  The bytes are
  * this compressor's own; what is pinned is that they inflate to exactly the text bp_render_fetch
  * returns. */
 int64_t bp_render_bgzf_bound(const bp_handle* h);

@@ -820,6 +820,12 @@ def test_rows_to_text_on_device():
                 per_row = [lines(kind, cols, names[r], int(pos[i]), int(seq[pos[i]]), vals[i]) for i in range(lo, hi)]
                 want = "".join("".join(x) for x in per_row).encode()
                 assert job.render_text(lo, hi - lo, kind, cols) == want, (r, kind, cols)
+                # the same lines as BGZF members from the device (bp_render_fetch_bgzf), both ways of calling it
+                import gzip
+                for how in ("one", "two"):
+                    z = job.render_text(lo, hi - lo, kind, cols, bgzf=how)
+                    assert (gzip.decompress(z) if want else z) == want, (r, kind, cols, how)
+                    assert len(z) < len(want) or len(want) < 200
                 # a sub-range that starts and ends inside tiles of the scan
                 a, b = lo + 700, min(hi, lo + 2900)
                 assert job.render_text(a, b - a, kind, cols) == "".join("".join(x) for x in per_row[a - lo:b - lo]).encode()

@@ -354,7 +354,6 @@ struct bp_handle {
   bool mate_dirty = true;                             // changed since it was last copied to the device
   FirstReadTable stored[kMatePartitions];  // by name hash (scan_slice)
   std::vector<PairOut> pair_out[kMatePartitions];
-  std::vector<uint32_t> lay_a, lay_q;  // bp_submit: payload part sizes of the call's records
   std::vector<PairItem> pair_items;   // of the slice, chunk by chunk, each chunk's in partition order
   std::vector<uint32_t> pair_start;   // [chunk][partition] -> first item; kMatePartitions + 1 entries a chunk
   std::vector<uint8_t> scan_cls;
@@ -1149,16 +1148,23 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
       (void)hipStreamSynchronize(h->stream);
     }
   } copy_fence{h, &wait_for_copy};
-  std::vector<int32_t> spans;
-  std::vector<uint8_t> simple;
-  std::vector<uint64_t> boff, qoff;
-  std::vector<uint32_t> gsrc;
+  // (the calling thread's own and kept between calls: a job's handle lives for one or two submits of
+  // a million records, and megabytes of fresh vectors per call are page faults and zero fills)
+  // (through references: a lambda run on a worker thread would otherwise name the WORKER's instance)
+  thread_local std::vector<int32_t> tl_spans;
+  thread_local std::vector<uint8_t> tl_simple;
+  thread_local std::vector<uint64_t> tl_boff, tl_qoff;
+  thread_local std::vector<uint32_t> tl_gsrc, tl_sz_a, tl_sz_q;
+  std::vector<int32_t>& spans = tl_spans;
+  std::vector<uint8_t>& simple = tl_simple;
+  std::vector<uint64_t>&boff = tl_boff, &qoff = tl_qoff;
+  std::vector<uint32_t>& gsrc = tl_gsrc;
   // a record longer than the core can say (0xffff) passes no max-read-len: no payload kept
   auto plen = [](uint32_t l) { return l > 0xffffu ? 0u : l; };
   // payload part sizes of every record of the call, on all threads: the layout loop below is
   // serial (a group closes when it is full) and otherwise spends its time working these out
-  std::vector<uint32_t>& sz_a = h->lay_a;
-  std::vector<uint32_t>& sz_q = h->lay_q;
+  std::vector<uint32_t>& sz_a = tl_sz_a;
+  std::vector<uint32_t>& sz_q = tl_sz_q;
   {
     const double t_sz = now_s();
     sz_a.resize((size_t)S.n);

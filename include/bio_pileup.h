@@ -332,7 +332,8 @@ int bp_inflate_timing(const bp_inflater* f, float* inflate_ms, float* crc_ms);
 /* The writer's side (the counterpart of bp_inflate; bgzf.Writer in the reference's output path,
  * output.go:70-71, :391): n bytes of host memory compressed on the inflater's device into complete
  * BGZF members of up to 0xff00 input bytes each, copied to `out` (at least bp_deflate_bgzf_bound(n)
- * bytes; no EOF member).  Synchronous. */
+ * bytes; no EOF member).  Synchronous.  The inflater keeps about 6 bytes of device memory per input
+ * byte of its largest call (tokens, member slots, output). */
 size_t bp_deflate_bgzf_bound(size_t n);
 /* The host half of that writer by itself (no device call; exported so that it can be tested without
  * one): from symbol counts hist[0..286) (literals, end of block, lengths; RFC 1951 3.2.5) and

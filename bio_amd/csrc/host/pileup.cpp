@@ -508,6 +508,8 @@ class Submitter {
     return err_;
   }
   double busy_s() const { return busy_s_; }
+  double release_s() const { return release_s_; }  // of busy_s: handing the pieces' buffers back
+  int64_t pieces() const { return pieces_; }
 
  private:
   void Run() {
@@ -524,8 +526,11 @@ class Submitter {
       }
       const double t0 = Now();
       std::string e = drv_->SubmitPiece(stream_, p);
+      const double t1 = Now();
       p = Piece();  // the chunk's buffer goes back to the reader's pool
       busy_s_ += Now() - t0;
+      release_s_ += Now() - t1;
+      pieces_++;
       std::unique_lock<std::mutex> lk(mu_);
       working_ = false;
       if (!e.empty() && err_.empty()) {
@@ -542,7 +547,8 @@ class Submitter {
   std::deque<Piece> q_;
   bool done_ = false, working_ = false;
   std::string err_;
-  double busy_s_ = 0;
+  double busy_s_ = 0, release_s_ = 0;
+  int64_t pieces_ = 0;
   std::thread th_;
 };
 
@@ -792,8 +798,11 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
     }
     return e;
   };
+  double open_s = 0;  // the main thread in OpenJob (handles created, BED and reference stretch uploaded)
   auto open_job = [&]() -> std::string {
+    const double t_open = Now();
     std::string e = drv.OpenJob(jobs[ji]);
+    open_s += Now() - t_open;
     open = e.empty();
     // what the job was given while the ones before it were open
     for (Piece& p : pend[0])
@@ -1059,10 +1068,10 @@ std::string Pileup(const std::string& xampath, const std::string& fapath, const 
   if (const char* e = getenv("BIO_PILEUP_STATS"); e && *e && *e != '0')
     fprintf(stderr,
             "bio-pileup stats: records_read=%lld records_kept=%lld seeks=%lld jobs=%lld index=%d "
-            "submit_s=%.3f (busy on its own thread; the reader waited %.3f s for it) close_s=%.3f (on its own "
+            "open_s=%.3f submit_s=%.3f (busy on its own thread, %lld pieces, %.3f s of it handing buffers back; the reader waited %.3f s for it) close_s=%.3f (on its own "
             "threads: compute %.3f, text out %.3f, handles freed %.3f; the reader waited %.3f s) read_s=%.3f (of which waiting for inflated blocks %.3f) device_inflate_s=%.3f stage_read_s=%.3f stage_inflate_s=%.3f (buffers %.3f) stage_scan_s=%.3f resident=%d (host walks %lld) total_s=%.3f (after %.3f s of set-up: header, BED, FASTA, device)\n",
             (long long)st.records_read, (long long)st.records_kept, (long long)st.seeks, (long long)st.jobs,
-            index.loaded() ? 1 : 0, submitters[0]->busy_s(), st.submit_s, st.close_s, cpart[0], cpart[1], cpart[2], st.close_wait_s,
+            index.loaded() ? 1 : 0, open_s, submitters[0]->busy_s(), (long long)submitters[0]->pieces(), submitters[0]->release_s(), st.submit_s, st.close_s, cpart[0], cpart[1], cpart[2], st.close_wait_s,
             st.total_s - st.submit_s - st.close_wait_s, bam.WaitSeconds(), bam.DeviceInflateSeconds(), sr, si, stk, ssc, resident ? 1 : 0, (long long)bam.ResidentFallbacks(), st.total_s, t_start - t_entry);
   return "";
 }

@@ -64,7 +64,13 @@ for mode in os.environ.get("E2E_MODES", "device,host").split(","):
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     wall = time.time() - t0
-    print(r.stderr.strip()[-2600:], flush=True)
+    prof = [ln for ln in r.stderr.splitlines() if ln.startswith("bp profile")]
+    if prof:  # BP_PROFILE=1: one line per job handle; their sums
+        import re
+        cols = np.array([[float(x) for x in re.findall(r" ([0-9.]+)", ln.split("s):")[1].split(";")[0])] for ln in prof])
+        print(f"bp profile, sums over {len(prof)} handles (extract layout scan-parallel scan-serial items ensure copy-wait total):",
+              cols.sum(axis=0).round(3).tolist(), flush=True)
+    print("\n".join(ln for ln in r.stderr.strip().splitlines() if not ln.startswith("bp profile"))[-2600:], flush=True)
     print(f"spawned at {t0:.3f}, returned at {t0 + wall:.3f} (epoch seconds)", flush=True)
     outs = sorted(p for p in os.listdir(d) if p.startswith("o."))
     size = sum(os.path.getsize(os.path.join(d, p)) for p in outs)

@@ -1245,7 +1245,8 @@ static int submit_records(bp_handle* h, const Src& S, const char* who) {
         if (int rc = acquire_stage(h, &st, true, direct ? 0 : (size_t)wanted)) return rc;
         if (!S.raw_dev)
           if (int rc = ensure(h, h->d_raw, (size_t)(direct ? extent : wanted) + 64, 0)) return rc;
-        if (int rc = ensure(h, h->d_pack, ns * sizeof(PackItem), 0)) return rc;
+        // (always a whole slice's worth, 16 MB: a size the cache of finished jobs' buffers always holds)
+        if (int rc = ensure(h, h->d_pack, kStageReads * sizeof(PackItem), 0)) return rc;
       }
       if (S.raw_dev) {
         // the records are on the device already: the pack kernel reads them where they lie, and the

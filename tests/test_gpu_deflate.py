@@ -95,3 +95,19 @@ def test_repeated_calls_reuse_the_buffers(inf):
     for seed, n in ((1, 50000), (2, 500), (3, 120000)):
         data = text_like(n, seed)
         assert gzip.decompress(bytes(inf.deflate(data))) == data
+
+
+def test_skewed_symbol_counts_use_length_limited_codes(inf):
+    """Fibonacci-like byte counts: Huffman's tree would be 30 deep, the codes are cut to 15 bits
+    (deflate_api.hip); shuffled, so that the literals carry the stream."""
+    rng = np.random.default_rng(8)
+    counts, a, b = [], 1, 1
+    for _ in range(31):
+        counts.append(a)
+        a, b = b, a + b
+    data = np.repeat(np.arange(31, dtype=np.uint8) + 48, counts)
+    rng.shuffle(data)
+    data = data.tobytes()
+    out = inf.deflate(data)
+    assert gzip.decompress(bytes(out)) == data
+    assert len(out) < len(data) / 2.5  # ~2.6 bits of entropy a byte

@@ -46,6 +46,8 @@ namespace {
 // window's own first position per hash 5.45x; four candidates 5.59x (tokeniser 3.2 -> 7 ms).
 constexpr int kWays = 4;          // candidates kept per hash: the last 1, 2 or 4 positions
 constexpr int kHashBits = kWays == 4 ? 10 : kWays == 2 ? 11 : 12;  // 8 KB of LDS per wave either way
+// (512 sets and 16 segments a member, for 28 waves a CU instead of 16: tokeniser 5.5 -> 3.7 ms on the 268 MB, 5.50x;
+// no difference end to end, so the ratio stays)
 constexpr bool kLazy = true;      // a longer match one byte on turns this byte into a literal
 constexpr bool kIntra = true;     // candidates inside the current window of 64 positions
 constexpr uint32_t kWarm = 512;
@@ -475,7 +477,7 @@ void launch_deflate_tokens(const uint8_t* text, uint64_t n_text, uint32_t* tok, 
                            hipStream_t s) {
   const uint64_t n_members = (n_text + kDflMember - 1) / kDflMember;
   if (n_members == 0) return;
-  hipLaunchKernelGGL(deflate_tokens_kernel, dim3((unsigned)(n_members * kDflSegs / 4)), dim3(256), 0, s, text, n_text, tok,
+  hipLaunchKernelGGL(deflate_tokens_kernel, dim3((unsigned)((n_members * kDflSegs + 3) / 4)), dim3(256), 0, s, text, n_text, tok,
                      ntok, hist);
 }
 void launch_deflate_encode(const uint8_t* text, uint64_t n_text, const uint32_t* tok, const uint32_t* ntok,

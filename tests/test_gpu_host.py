@@ -268,8 +268,12 @@ def test_bgz_by_the_device_and_by_the_host_inflate_to_the_plain_files(tmp_path, 
     bytes; small jobs make many short runs of members."""
     import gzip
     c = Case(tmp_path, seed=31)
-    for fmt, names in (("basestrand-tsv", ["basestrand.tsv"]), ("tsv", ["ref.tsv", "alt.tsv"])):
-        o = Opts(BedPath=c.bed_path, Cols="dpref,dpalt") if fmt == "tsv" else Opts(BedPath=c.bed_path)
+    cases = (("basestrand-tsv", ["basestrand.tsv"], Opts(BedPath=c.bed_path)),
+             ("tsv", ["ref.tsv", "alt.tsv"], Opts(BedPath=c.bed_path, Cols="dpref,dpalt")),
+             # -per-strand in one pass: two files from one handle, each its strand's share of the rows
+             ("tsv", ["strand.fwd.ref.tsv", "strand.fwd.alt.tsv", "strand.rev.ref.tsv", "strand.rev.alt.tsv"],
+              Opts(BedPath=c.bed_path, PerStrand=True)))
+    for fmt, names, o in cases:
         host.pileup(c.bam, c.fa, fmt, str(tmp_path / "p"), o)
         monkeypatch.setenv("BIO_PILEUP_JOB_SPAN", "900")
         host.pileup(c.bam, c.fa, fmt + "-bgz", str(tmp_path / "d"), o)

@@ -613,7 +613,11 @@ struct BamReader::Impl {
                            U32(R.raw.data() + b.off + b.clen)});
     const size_t nb = blk_tab.size();
     if (nb == 0) return;
-    const size_t parts = std::min<size_t>(kDeviceParts, std::max<size_t>(1, nb / 256));
+    // Parts pay when the output travels back to the host beside the next part's kernel.  When it stays
+    // on the device one launch is best: chr1 30x -bgz end to end 1.06 s with 1 part, 1.10 / 1.13 / 1.15 /
+    // 1.47 s with 2 / 3 / 4 / 8 (same box, alternating) - a batch takes one block's decode time however
+    // it is cut, and more streams only stand in each other's way and in the scan's.
+    const size_t parts = out_dev ? 1 : std::min<size_t>(kDeviceParts, std::max<size_t>(1, nb / 256));
     while (inflaters.size() < std::max<size_t>(parts, 1)) {
       bp_inflater* x = nullptr;
       if (bp_inflate_create(idev, &x) != BP_OK) { *err = bp_inflate_last_error(nullptr); return; }

@@ -5,8 +5,8 @@
 namespace bp {
 
 constexpr int kDflMember = 0xff00;               // text bytes per BGZF member (what bgzip and hts' bgzf.Writer use)
-constexpr int kDflSegs = 8;                      // a member is tokenised in this many segments, a wave each
-constexpr int kDflSeg = kDflMember / kDflSegs;   // 8160 bytes
+constexpr int kDflSegs = 32;                     // a member is tokenised in this many segments, a wave each
+constexpr int kDflSeg = kDflMember / kDflSegs;   // 2040 bytes
 constexpr int kDflSlot = 65536 + 512;            // bytes a member has to itself before the members are packed (a member is given
                                                  // up for the stored form only after the step that made it too long: 384 bytes more)
 constexpr int kDflHist = 320;                    // [0, 286) literal/length symbols, [288, 318) distance symbols

@@ -8,10 +8,10 @@
 // the device (text_write_kernel), so compressing them there means a fifth of the bytes cross the
 // bus and reach the file, and no host thread deflates.
 //
-//   deflate_tokens_kernel   LZ77.  A member (0xff00 bytes of text) is cut into 8 segments, a WAVE
+//   deflate_tokens_kernel   LZ77.  A member (0xff00 bytes of text) is cut into 32 segments, a WAVE
 //                           each.  64 consecutive positions per step, lane = position: hash of the
 //                           4 bytes there, candidates = the last four earlier positions with that
-//                           hash (LDS table of 1024 x 4 16-bit positions per wave, primed with the
+//                           hash (LDS table of 512 x 4 16-bit positions per wave, primed with the
 //                           512 bytes in front of the segment) and the window's own first position
 //                           with it, match lengths by comparing dwords, the longest wins; a longer
 //                           match one byte on makes this byte a literal (one step of zlib's lazy rule).
@@ -45,9 +45,12 @@ namespace {
 // one candidate per hash 4.90x; + one step of lazy evaluation 5.11x; two candidates 5.34x; + the
 // window's own first position per hash 5.45x; four candidates 5.59x (tokeniser 3.2 -> 7 ms).
 constexpr int kWays = 4;          // candidates kept per hash: the last 1, 2 or 4 positions
-constexpr int kHashBits = kWays == 4 ? 10 : kWays == 2 ? 11 : 12;  // 8 KB of LDS per wave either way
-// (512 sets and 16 segments a member, for 28 waves a CU instead of 16: tokeniser 5.5 -> 3.7 ms on the 268 MB, 5.50x;
-// no difference end to end, so the ratio stays)
+constexpr int kHashBits = 9;      // sets of the table: 512 x 4 positions = 4 KB of LDS per wave
+// Table size and segment length against a whole run (chr1 30x basestrand-tsv-bgz end to end, same box,
+// alternating libraries; ratio on the 268 MB of lines): 1,024 sets and 8 segments a member 1.06 s 5.59x;
+// 512 / 16: 0.99 s 5.50x; 256 / 16: 0.98 s 5.46x; 512 / 32: 0.96 s 5.47x; 256 / 32: 0.95 s 5.44x.  The run is
+// bound by the device's total kernel time: more and shorter waves (28 a CU instead of 16) fill the gaps
+// the reader's and the jobs' kernels leave, and a chunk's tokeniser finishes in a third of the time.
 constexpr bool kLazy = true;      // a longer match one byte on turns this byte into a literal
 constexpr bool kIntra = true;     // candidates inside the current window of 64 positions
 constexpr uint32_t kWarm = 512;

@@ -46,8 +46,9 @@ def inf():
         yield f
 
 
-@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 63, 64, 65, 8159, 8160, 8161, 0xff00 - 1, 0xff00, 0xff00 + 1, 3 * 0xff00 + 77])
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 63, 64, 65, 2039, 2040, 2041, 4080, 8159, 8160, 8161, 0xff00 - 1, 0xff00, 0xff00 + 1, 3 * 0xff00 + 77])
 def test_sizes_around_every_boundary(inf, n):
+    # (windows of 64 positions, segments of 2,040 bytes - a wave each -, members of 0xff00)
     data = text_like(n // 20 + 2, n)[:n]
     out = inf.deflate(data)
     ms = members(out)
